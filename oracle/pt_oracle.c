@@ -1,0 +1,636 @@
+/*
+ * oracle/pt_oracle.c -- TEST INFRASTRUCTURE (checker only; see pt_oracle.h).
+ *
+ * CPU restatement, in plain C, of the Assign10 path-tracing kernels of
+ * eaymerich/2015-RayTracing.  Every function cites the reference lines it
+ * follows ("A10 code.cl:NNN" = Assign10-Path_Tracing/code.cl).  Arithmetic
+ * follows oracle/cl_numerics.h (IEEE binary32, no contraction, explicit
+ * evaluation order); vector expressions are spelled out component-wise in the
+ * order OpenCL C evaluates them (left to right, scalar*scalar before
+ * scalar*vector where the source does so).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no fast-math).
+ */
+#include "pt_oracle.h"
+#include "cl_numerics.h"
+
+#include <limits.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- flop accounting ---------------------------------------- */
+#ifdef PTO_COUNT_FLOPS
+static unsigned long long g_flops;
+#define FL(n) (g_flops += (unsigned long long)(n))
+unsigned long long oracle_flops_get(void) { return g_flops; }
+void oracle_flops_reset(void) { g_flops = 0; }
+#else
+#define FL(n) ((void)0)
+unsigned long long oracle_flops_get(void) { return 0; }
+void oracle_flops_reset(void) {}
+#endif
+
+int oracle_num_threads(void) {
+#if defined(_OPENMP) && !defined(PTO_COUNT_FLOPS)
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void oracle_set_threads(int n) {
+#if defined(_OPENMP) && !defined(PTO_COUNT_FLOPS)
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+#if defined(_OPENMP) && !defined(PTO_COUNT_FLOPS)
+#define PAR_FOR _Pragma("omp parallel for schedule(static, 4096)")
+#else
+#define PAR_FOR
+#endif
+
+/* ---- small vector layer -------------------------------------------------- */
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
+static inline void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+static inline v3 add(v3 a, v3 b) { FL(3); return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { FL(3); return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mulv(v3 a, v3 b) { FL(3); return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 scl(float s, v3 a) { FL(3); return V(s * a.x, s * a.y, s * a.z); }
+static inline float dot3(v3 a, v3 b) {
+    FL(5);
+    float s = a.x * b.x;
+    s = s + a.y * b.y;
+    s = s + a.z * b.z;
+    return s;
+}
+static inline v3 cross3(v3 a, v3 b) {
+    FL(9);
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float len3(v3 a) { FL(1); return cln_sqrt(dot3(a, a)); }
+static inline v3 norm3(v3 a) {
+    FL(5);
+    float inv = 1.0f / cln_sqrt(dot3(a, a));
+    return V(a.x * inv, a.y * inv, a.z * inv);
+}
+
+#define PT_INF (__builtin_inff())
+#define PI_4_F 0.785398163397448309616f
+#define PI_2_F 1.57079632679489661923f
+
+typedef struct { v3 o, d; float mint, maxt; } ray_t;
+typedef struct { v3 pmin, pmax; } box_t;
+typedef struct { v3 eye, U, V, W; float width, height; uint32_t cols, rows; } cam_t;
+
+static inline ray_t ld_ray(const pto_ray* r) { ray_t q = {ld3(r->o), ld3(r->d), r->mint, r->maxt}; return q; }
+static inline void st_ray(pto_ray* r, ray_t q) { st3(r->o, q.o); st3(r->d, q.d); r->mint = q.mint; r->maxt = q.maxt; }
+static inline box_t ld_box(const float* b8) { box_t b = {ld3(b8), ld3(b8 + 4)}; return b; }
+
+/* A10 code.cl:73-84 floatToCamera */
+static cam_t ld_cam(const float* f) {
+    cam_t c;
+    c.eye = ld3(f); c.U = ld3(f + 3); c.V = ld3(f + 6); c.W = ld3(f + 9);
+    c.width = f[12]; c.height = f[13];
+    c.cols = cln_f2u(f[14]); c.rows = cln_f2u(f[15]);
+    return c;
+}
+
+/* ---- RNG: A10 code.cl:420-434 -------------------------------------------- */
+/* seed' = ((long)(int32)(seed * 16807)) % 2147483647 : the product wraps in
+ * int32 BEFORE widening, the remainder is C's truncating one (sign follows
+ * the dividend), so states go negative. */
+static inline int32_t lcg_next(int32_t s) {
+    int32_t w = (int32_t)((uint32_t)s * 16807u);
+    return (int32_t)((int64_t)w % 2147483647LL);
+}
+int oracle_a10_rand(int* seed) { *seed = lcg_next(*seed); return *seed; }
+
+static inline float get_rand(int* slot) {
+    const float im = 1.0f / 2147483647.0f; /* == 2^-31 after rounding the divisor */
+    int32_t s = lcg_next(*slot);
+    *slot = s;
+    FL(1);
+    return cln_fabs((float)s * im);
+}
+
+/* ---- camera: A10 code.cl:108-119, 143-197 -------------------------------- */
+static ray_t get_ray(const cam_t* c, float col, float row) {
+    FL(8);
+    float sx = (-0.5f + (col + 0.5f) / (float)c->cols) * c->width;
+    float sy = (0.5f - (row + 0.5f) / (float)c->rows) * c->height;
+    v3 cop = add(add(scl(sx, c->U), scl(sy, c->V)), scl(-1.0f, c->W));
+    ray_t r;
+    r.d = norm3(cop);
+    r.o = c->eye;
+    r.mint = 0.0f;
+    r.maxt = PT_INF;
+    return r;
+}
+
+/* Shirley-Chiu concentric map as the reference spells it (code.cl:143-172) */
+static void concentric(float inx, float iny, float* ox, float* oy) {
+    if (inx == 0.0f && iny == 0.0f) { *ox = inx; *oy = iny; return; }
+    float phi, radius;
+    FL(6);
+    float a = (2.0f * inx) - 1.0f;
+    float b = (2.0f * iny) - 1.0f;
+    if ((a * a) > (b * b)) {
+        FL(3);
+        radius = 1.0f * a;
+        phi = PI_4_F * (b / a);
+    } else {
+        FL(4);
+        radius = 1.0f * b;
+        phi = PI_2_F - (PI_4_F * (a / b));
+    }
+    float s, c;
+    cln_sincos(phi, &s, &c);
+    FL(4);
+    *ox = c * radius;
+    *oy = s * radius;
+}
+
+/* code.cl:174-181 */
+static v3 focal_point(const cam_t* c, float col, float row, float focal_length) {
+    ray_t r = get_ray(c, col, row);
+    v3 pip = add(c->eye, scl(-1.0f, scl(focal_length, c->W)));
+    v3 N = c->W;
+    FL(2);
+    float d = -dot3(pip, N);
+    float t = -(dot3(r.o, N) + d) / dot3(r.d, N);
+    return add(r.o, scl(t, r.d));
+}
+
+/* code.cl:183-197 */
+static ray_t thin_lens_ray(const cam_t* c, v3 fp, float lens_rad, float cx, float cy) {
+    ray_t r;
+    r.mint = 0.0f;
+    r.maxt = PT_INF;
+    float dx, dy;
+    concentric(cx, cy, &dx, &dy);
+    FL(2);
+    dx = dx * lens_rad;
+    dy = dy * lens_rad;
+    r.o = add(add(c->eye, scl(dx, c->U)), scl(dy, c->V));
+    r.d = norm3(sub(fp, r.o));
+    return r;
+}
+
+/* ---- ray / box: A10 code.cl:335-389 -------------------------------------- */
+typedef struct { float tmin, tmax; int v; } boxhit_t;
+
+static boxhit_t inter_aabb(const ray_t* r, const box_t* b) {
+    boxhit_t h;
+    h.tmin = 0.0f;
+    h.tmax = PT_INF;
+    h.v = 0;
+    const float lo[3] = {b->pmin.x, b->pmin.y, b->pmin.z};
+    const float hi[3] = {b->pmax.x, b->pmax.y, b->pmax.z};
+    const float o[3] = {r->o.x, r->o.y, r->o.z};
+    const float d[3] = {r->d.x, r->d.y, r->d.z};
+    for (int k = 0; k < 3; ++k) {
+        FL(4);
+        float t0 = (lo[k] - o[k]) / d[k];
+        float t1 = (hi[k] - o[k]) / d[k];
+        if (d[k] < 0) { float tmp = t0; t0 = t1; t1 = tmp; }
+        h.tmin = cln_max(t0, h.tmin);
+        h.tmax = cln_min(t1, h.tmax);
+        if (h.tmin > h.tmax) return h;
+    }
+    h.v = 1;
+    return h;
+}
+
+/* ---- primitives ---------------------------------------------------------- */
+/* code.cl:199-242; sph[3] holds r^2 (host pushes rad*rad, code.js:1602) */
+static int inter_sphere(const ray_t* r, const float* sph, float* t_out) {
+    v3 omc = sub(r->o, ld3(sph));
+    float a = dot3(r->d, r->d);
+    FL(6);
+    float b = 2.0f * dot3(omc, r->d);
+    float c = dot3(omc, omc) - sph[3];
+    float dis = cln_mad(-4.0f * c, a, b * b);
+    if (dis < 0.0f) { *t_out = PT_INF; return 0; }
+    FL(7);
+    a = 1.0f / (2.0f * a);
+    dis = cln_sqrt(dis);
+    float t0 = (-b - dis) * a;
+    float t1 = (-b + dis) * a;
+    float tmin = cln_fmin(t0, t1);
+    float tmax = cln_fmax(t0, t1);
+    if (tmin >= r->mint && tmin <= r->maxt) { *t_out = tmin; return 1; }
+    if (tmax >= r->mint && tmax <= r->maxt) { *t_out = tmax; return 1; }
+    return 0;
+}
+
+/* code.cl:250-288: Moeller-Trumbore, single-sided (div <= 0 rejects) */
+static int inter_triangle(const ray_t* r, const float* tp /* 3 x float4 */, float* t_out, float* beta_out, float* gamma_out) {
+    v3 p0 = ld3(tp), p1 = ld3(tp + 4), p2 = ld3(tp + 8);
+    v3 e1 = sub(p1, p0);
+    v3 e2 = sub(p2, p0);
+    float div = dot3(cross3(e2, e1), r->d);
+    if (div <= 0) return 0;
+    FL(2);
+    float idiv = 1.0f / div;
+    v3 s = sub(r->o, p0);
+    float beta = dot3(cross3(s, r->d), e2) * idiv;
+    if (beta < 0.0f || beta > 1.0f) return 0;
+    FL(1);
+    float gamma = dot3(cross3(s, e1), r->d) * idiv;
+    FL(1);
+    float gb = gamma + beta;
+    if (gamma < 0.0f || gb < 0.0f || gb > 1.0f) return 0;
+    FL(1);
+    float t = dot3(cross3(s, e2), e1) * -idiv;
+    if (t >= r->mint && t <= r->maxt) { *t_out = t; *beta_out = beta; *gamma_out = gamma; return 1; }
+    return 0;
+}
+
+/* ---- 3-D uniform grid DDA: the text repeated at A10 code.cl:694-786,
+ *      822-919, 957-1054, 1090-1183, 1213-1310 ------------------------------ */
+typedef struct {
+    int slab, dslab, limit;
+    float dt, tnext;
+} axis_t;
+
+static axis_t axis_setup(float o, float d, float tmin, float lo, float hi, uint32_t n) {
+    axis_t a;
+    FL(11);
+    float x = o + tmin * d;
+    float delta = (hi - lo) / (float)n;
+    a.slab = cln_f2i((x - lo) / delta);
+    if (a.slab < 0) a.slab = 0;
+    if ((uint32_t)a.slab >= n) a.slab = (int)(n - 1u);
+    a.dslab = (d >= 0) ? 1 : -1;
+    a.limit = (d >= 0) ? (int)n : -1;
+    a.dt = delta / cln_fabs(d);
+    float xnext = lo + (float)(a.slab + ((d >= 0) ? 1 : 0)) * delta;
+    a.tnext = (xnext - o) / d;
+    return a;
+}
+
+enum { PRIM_SPHERE = 0, PRIM_TRIANGLE = 1 };
+
+typedef struct {
+    uint32_t idx;   /* UINT_MAX = none */
+    float t, beta, gamma;
+} champ_t;
+
+/* Walks the grid front to back and stops at the first cell that produced a hit.
+ * any_hit: leave the cell scan at the first accepted primitive (shadow kernels). */
+static champ_t grid_trace(ray_t ray /* by value: mint/maxt are clobbered per cell */, boxhit_t bh, const box_t* bound,
+                          uint32_t n, const uint32_t* cell_off, const float* prims, int kind, int any_hit) {
+    axis_t ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, bound->pmin.x, bound->pmax.x, n);
+    axis_t ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, bound->pmin.y, bound->pmax.y, n);
+    axis_t az = axis_setup(ray.o.z, ray.d.z, bh.tmin, bound->pmin.z, bound->pmax.z, n);
+    champ_t ch;
+    ch.idx = UINT_MAX;
+    ch.t = ray.maxt;
+    ch.beta = ch.gamma = 0.0f;
+    float t = bh.tmin;
+    const uint32_t zs = n * n, ys = n;
+    for (;;) {
+        ray.mint = t;
+        ray.maxt = cln_min(cln_min(ax.tnext, ay.tnext), az.tnext);
+        uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
+        uint32_t begin = cell_off[cell], end = cell_off[cell + 1];
+        for (uint32_t i = begin; i < end; ++i) {
+            float ti, b = 0.0f, g = 0.0f;
+            int hit = (kind == PRIM_SPHERE) ? inter_sphere(&ray, prims + 4u * (size_t)i, &ti)
+                                            : inter_triangle(&ray, prims + 12u * (size_t)i, &ti, &b, &g);
+            if (hit && ti < ch.t) {
+                ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = g;
+                if (any_hit) break;
+            }
+        }
+        if (ch.idx < UINT_MAX) break;
+        t = ray.maxt;
+        if (t == ax.tnext) {
+            FL(1);
+            ax.tnext += ax.dt;
+            if (t >= bh.tmax) break;
+            ax.slab += ax.dslab;
+            if (ax.slab == ax.limit) break;
+        } else if (t == ay.tnext) {
+            FL(1);
+            ay.tnext += ay.dt;
+            if (t >= bh.tmax) break;
+            ay.slab += ay.dslab;
+            if (ay.slab == ay.limit) break;
+        } else {
+            FL(1);
+            az.tnext += az.dt;
+            if (t >= bh.tmax) break;
+            az.slab += az.dslab;
+            if (az.slab == az.limit) break;
+        }
+    }
+    return ch;
+}
+
+/* ---- kernels ------------------------------------------------------------- */
+unsigned oracle_a10_sizeofRay(void) { return (unsigned)sizeof(pto_ray); } /* code.cl:440-442 */
+unsigned oracle_a10_sizeofPoi(void) { return (unsigned)sizeof(pto_poi); } /* code.cl:444-446 */
+
+/* code.cl:448-456 */
+void oracle_a10_initAcu(void* acu_, unsigned total, size_t gsz) {
+    float* acu = (float*)acu_;
+    size_t n = gsz < total ? gsz : total;
+    PAR_FOR
+    for (size_t id = 0; id < n; ++id) {
+        acu[4 * id + 0] = 0.0f; acu[4 * id + 1] = 0.0f; acu[4 * id + 2] = 0.0f; acu[4 * id + 3] = 0.0f;
+    }
+}
+
+static void clip_and_store(pto_ray* dst, ray_t ray, const box_t* bound) {
+    boxhit_t h = inter_aabb(&ray, bound);
+    if (h.v) { ray.mint = h.tmin; ray.maxt = h.tmax; }
+    else { ray.mint = ray.maxt; }
+    st_ray(dst, ray);
+}
+
+/* code.cl:458-543.  2-D NDRange, work-items in row-major order; with rpp == 1
+ * the two lens draws come from seeds[col] (get_global_id(0) inside a 2-D
+ * launch), i.e. row r of column c consumes draws 2r+1, 2r+2 of that stream. */
+void oracle_a10_initTrace(int* seeds, void* rays_, void* pois_, const float* bound8, const float* cam16,
+                          float focal_length, float lens_rad, unsigned rpp, size_t gx, size_t gy) {
+    cam_t cam = ld_cam(cam16);
+    box_t bound = ld_box(bound8);
+    pto_ray* rays = (pto_ray*)rays_;
+    pto_poi* pois = (pto_poi*)pois_;
+    for (size_t row = 0; row < gy; ++row) {
+        for (size_t col = 0; col < gx; ++col) {
+            if (col >= cam.cols || row >= cam.rows) continue;
+            size_t base = ((size_t)cam.cols * row + col) * rpp;
+            v3 fp = focal_point(&cam, (float)(uint32_t)col, (float)(uint32_t)row, focal_length);
+            if (rpp > 1) {
+                FL(3);
+                uint32_t side = cln_f2u(cln_sqrt((float)rpp));
+                float delta = 1.0f / (float)side;
+                float cy = delta / 2.0f;
+                for (uint32_t i = 0; i < side; ++i) {
+                    FL(1);
+                    float cx = delta / 2.0f;
+                    for (uint32_t j = 0; j < side; ++j) {
+                        clip_and_store(&rays[base + (size_t)i * side + j], thin_lens_ray(&cam, fp, lens_rad, cx, cy), &bound);
+                        FL(1);
+                        cx += delta;
+                    }
+                    FL(1);
+                    cy += delta;
+                }
+            } else {
+                float cy = get_rand(&seeds[col]);
+                float cx = get_rand(&seeds[col]);
+                clip_and_store(&rays[base], thin_lens_ray(&cam, fp, lens_rad, cx, cy), &bound);
+            }
+            for (unsigned i = 0; i < rpp; ++i) {
+                pois[base + i].matId = -1;
+                pois[base + i].atte[0] = 1.0f; pois[base + i].atte[1] = 1.0f; pois[base + i].atte[2] = 1.0f;
+            }
+        }
+    }
+}
+
+/* code.cl:545-598 */
+void oracle_a10_bouncePaths(void* pois_, void* rays_, int* seeds, unsigned total, size_t gsz) {
+    const pto_poi* pois = (const pto_poi*)pois_;
+    pto_ray* rays = (pto_ray*)rays_;
+    size_t n = gsz < total ? gsz : total;
+    PAR_FOR
+    for (size_t id = 0; id < n; ++id) {
+        const pto_poi* poi = &pois[id];
+        if (poi->matId >= 0) {
+            v3 nrm = ld3(poi->n);
+            v3 N = V(cln_fabs(nrm.x), cln_fabs(nrm.y), cln_fabs(nrm.z));
+            v3 B = nrm;
+            float nmin = cln_min(cln_min(N.x, N.y), N.z);
+            if (N.x == nmin) B.x = 1.0f;
+            else if (N.y == nmin) B.y = 1.0f;
+            else B.z = 1.0f;
+            N = nrm;
+            B = norm3(B);
+            v3 T = cross3(B, N);
+            B = cross3(N, T);
+            float sx = get_rand(&seeds[id]);
+            float sy = get_rand(&seeds[id]);
+            concentric(sx, sy, &sx, &sy);
+            FL(5);
+            float sz = cln_sqrt(cln_max(0.0f, 1.0f - sx * sx - sy * sy));
+            ray_t r;
+            r.o = ld3(poi->p);
+            r.d = norm3(add(add(scl(sx, T), scl(sy, B)), scl(sz, N)));
+            r.mint = 0.0f;
+            r.maxt = PT_INF;
+            st_ray(&rays[id], r);
+        } else {
+            /* the reference stores an otherwise uninitialised Ray here; only mint/maxt are defined */
+            rays[id].mint = PT_INF;
+            rays[id].maxt = PT_INF;
+        }
+    }
+}
+
+/* code.cl:391-403, 600-629 */
+void oracle_a10_lightRender(void* pois_, void* rays_, void* acu_, const float* light, unsigned total, size_t gsz) {
+    pto_poi* pois = (pto_poi*)pois_;
+    pto_ray* rays = (pto_ray*)rays_;
+    float* acu = (float*)acu_;
+    size_t n = gsz < total ? gsz : total;
+    v3 lpos = ld3(light), lnor = ld3(light + 3);
+    float radius = light[9];
+    PAR_FOR
+    for (size_t id = 0; id < n; ++id) {
+        ray_t ray = ld_ray(&rays[id]);
+        if (ray.mint == ray.maxt) continue;
+        v3 irr = norm3(ld3(light + 6));
+        float den = dot3(ray.d, lnor);
+        if (den == 0.0f) continue;
+        float num = dot3(sub(lpos, ray.o), lnor);
+        if (num == 0.0f) continue;
+        FL(1);
+        float t = num / den;
+        v3 p = add(ray.o, scl(t, ray.d));
+        if (len3(sub(p, lpos)) > radius) continue;
+        if (t >= ray.maxt) continue;
+        rays[id].mint = PT_INF;
+        rays[id].maxt = PT_INF;
+        pois[id].matId = -1;
+        FL(4);
+        acu[4 * id + 0] += irr.x; acu[4 * id + 1] += irr.y; acu[4 * id + 2] += irr.z; acu[4 * id + 3] += 1.0f;
+    }
+}
+
+/* code.cl:121-129, 631-673 */
+void oracle_a10_initShadowTrace(void* shadow_, void* pois_, unsigned total, const float* light, int* seeds, size_t gsz) {
+    pto_ray* shadow = (pto_ray*)shadow_;
+    const pto_poi* pois = (const pto_poi*)pois_;
+    size_t n = gsz < total ? gsz : total;
+    v3 lpos0 = ld3(light), T = ld3(light + 3), B = ld3(light + 6);
+    float radius = light[9];
+    PAR_FOR
+    for (size_t id = 0; id < n; ++id) {
+        const pto_poi* poi = &pois[id];
+        if (poi->matId < 0) {
+            shadow[id].mint = PT_INF;
+            shadow[id].maxt = PT_INF;
+            continue;
+        }
+        v3 p = add(ld3(poi->p), scl(0.001f, ld3(poi->n)));
+        float x = get_rand(&seeds[id]);
+        float y = get_rand(&seeds[id]);
+        concentric(x, y, &x, &y);
+        FL(2);
+        x = x * radius;
+        y = y * radius;
+        v3 lpos = add(lpos0, add(scl(x, T), scl(y, B)));
+        ray_t r;
+        v3 to = sub(lpos, p);
+        r.o = p;
+        r.d = norm3(to);
+        r.mint = 0.0f;
+        r.maxt = len3(sub(lpos, p));
+        st_ray(&shadow[id], r);
+    }
+}
+
+static void closest_kernel(unsigned total, pto_poi* pois, pto_ray* rays, const float* prims, const float* normals,
+                           const unsigned* matid, unsigned mesh_matid, const unsigned* cell_off, const float* bound8,
+                           unsigned n_slabs, size_t gsz, int kind) {
+    box_t bound = ld_box(bound8);
+    size_t n = gsz < total ? gsz : total;
+    PAR_FOR
+    for (size_t id = 0; id < n; ++id) {
+        ray_t ray = ld_ray(&rays[id]);
+        if (ray.mint == ray.maxt) continue;
+        boxhit_t bh = inter_aabb(&ray, &bound);
+        if (!bh.v) continue;
+        champ_t ch = grid_trace(ray, bh, &bound, n_slabs, cell_off, prims, kind, 0);
+        if (ch.idx == UINT_MAX) continue;
+        rays[id].maxt = ch.t;
+        v3 p = add(ray.o, scl(ch.t, ray.d));
+        v3 nrm;
+        if (kind == PRIM_SPHERE) {
+            nrm = norm3(sub(p, ld3(prims + 4u * (size_t)ch.idx)));       /* code.cl:794-797 */
+        } else {
+            const float* nn = normals + 12u * (size_t)ch.idx;             /* code.cl:405-411, 927-931 */
+            FL(2);
+            float w = 1.0f - ch.beta - ch.gamma;
+            nrm = norm3(add(add(scl(w, ld3(nn)), scl(ch.beta, ld3(nn + 4))), scl(ch.gamma, ld3(nn + 8))));
+        }
+        /* trace kernels write p, normal, matId -- never atte (SURVEY 8a hazard 2) */
+        st3(pois[id].p, p);
+        st3(pois[id].n, nrm);
+        pois[id].matId = (int32_t)(matid ? matid[ch.idx] : mesh_matid);
+    }
+}
+
+/* code.cl:675-800 */
+void oracle_a10_sphereTrace(unsigned total, void* pois, void* rays, void* spheres, unsigned* matid,
+                            unsigned* box, const float* bound, unsigned n, size_t gsz) {
+    closest_kernel(total, (pto_poi*)pois, (pto_ray*)rays, (const float*)spheres, NULL, matid, 0, box, bound, n, gsz, PRIM_SPHERE);
+}
+/* code.cl:802-935 */
+void oracle_a10_triangleTrace(unsigned total, void* pois, void* rays, void* pos, void* nor, unsigned* matid,
+                              unsigned* box, const float* bound, unsigned n, size_t gsz) {
+    closest_kernel(total, (pto_poi*)pois, (pto_ray*)rays, (const float*)pos, (const float*)nor, matid, 0, box, bound, n, gsz, PRIM_TRIANGLE);
+}
+/* code.cl:937-1070 */
+void oracle_a10_meshTrace(unsigned total, void* pois, void* rays, void* pos, void* nor, unsigned* box,
+                          unsigned matid, const float* bound, unsigned n, size_t gsz) {
+    closest_kernel(total, (pto_poi*)pois, (pto_ray*)rays, (const float*)pos, (const float*)nor, NULL, matid, box, bound, n, gsz, PRIM_TRIANGLE);
+}
+
+static void anyhit_kernel(unsigned total, pto_ray* shadow, const float* prims, const unsigned* cell_off,
+                          const float* bound8, unsigned n_slabs, size_t gsz, int kind) {
+    box_t bound = ld_box(bound8);
+    size_t n = gsz < total ? gsz : total;
+    PAR_FOR
+    for (size_t id = 0; id < n; ++id) {
+        ray_t ray = ld_ray(&shadow[id]);
+        if (ray.mint == ray.maxt) continue;
+        boxhit_t bh = inter_aabb(&ray, &bound);
+        if (!bh.v) continue;
+        champ_t ch = grid_trace(ray, bh, &bound, n_slabs, cell_off, prims, kind, 1);
+        shadow[id].maxt = ch.t;                       /* free way: unchanged value re-stored (code.cl:1189-1192) */
+        if (ch.idx != UINT_MAX) shadow[id].mint = ch.t; /* blocked: mint == maxt marks the ray dead */
+    }
+}
+
+/* code.cl:1073-1193 */
+void oracle_a10_sphereShadowTrace(unsigned total, void* shadow, void* spheres, unsigned* box,
+                                  const float* bound, unsigned n, size_t gsz) {
+    anyhit_kernel(total, (pto_ray*)shadow, (const float*)spheres, box, bound, n, gsz, PRIM_SPHERE);
+}
+/* code.cl:1195-1321 */
+void oracle_a10_triangleShadowTrace(unsigned total, void* shadow, void* pos, unsigned* box,
+                                    const float* bound, unsigned n, size_t gsz) {
+    anyhit_kernel(total, (pto_ray*)shadow, (const float*)pos, box, bound, n, gsz, PRIM_TRIANGLE);
+}
+
+/* code.cl:1323-1364 */
+void oracle_a10_sceneRender(void* acu_, void* pois_, void* shadow_, void* material_, const float* light,
+                            unsigned total, size_t gsz) {
+    float* acu = (float*)acu_;
+    pto_poi* pois = (pto_poi*)pois_;
+    const pto_ray* shadow = (const pto_ray*)shadow_;
+    const float* material = (const float*)material_;
+    size_t n = gsz < total ? gsz : total;
+    v3 lpos = ld3(light), lnor = ld3(light + 3), es = ld3(light + 6);
+    float area = light[9];
+    PAR_FOR
+    for (size_t id = 0; id < n; ++id) {
+        pto_poi* poi = &pois[id];
+        if (poi->matId < 0) continue;
+        v3 shade = V(0.0f, 0.0f, 0.0f);
+        if (shadow[id].maxt != shadow[id].mint) {
+            v3 sd = ld3(shadow[id].d);
+            float r = len3(sub(ld3(poi->p), lpos));
+            float cosx = cln_clamp(dot3(sd, ld3(poi->n)), 0.0f, 1.0f);
+            float cosy = cln_clamp(dot3(V(-sd.x, -sd.y, -sd.z), lnor), 0.0f, 1.0f);
+            FL(4);
+            shade = scl(area * ((cosx * cosy) / (r * r)), es);
+        }
+        v3 color = ld3(material + 4u * (size_t)poi->matId);
+        v3 atte = ld3(poi->atte);
+        st3(poi->atte, mulv(atte, color));
+        v3 c = mulv(mulv(color, atte), shade);
+        FL(4);
+        acu[4 * id + 0] += c.x; acu[4 * id + 1] += c.y; acu[4 * id + 2] += c.z; acu[4 * id + 3] += 1.0f;
+    }
+}
+
+/* code.cl:1366-1386 */
+void oracle_a10_copyToPixel(void* pixel_, void* acu_, float m, unsigned pixels, unsigned rpp, size_t gsz) {
+    uint8_t* pixel = (uint8_t*)pixel_;
+    const float* acu = (const float*)acu_;
+    size_t n = gsz < pixels ? gsz : pixels;
+    PAR_FOR
+    for (size_t id = 0; id < n; ++id) {
+        const float* a = acu + 4u * id * (size_t)rpp;
+        float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (unsigned i = 0; i < rpp; ++i)
+            for (int k = 0; k < 4; ++k) { FL(1); c[k] = c[k] + a[4u * i + k]; }
+        FL(1);
+        float s = 255.0f * m;
+        for (int k = 0; k < 4; ++k) {
+            FL(2);
+            c[k] = c[k] * s;
+            c[k] = c[k] * 1.8f;
+            c[k] = cln_clamp(c[k], 0.0f, 255.0f);
+        }
+        pixel[4 * id + 0] = (uint8_t)cln_f2u(c[0]);
+        pixel[4 * id + 1] = (uint8_t)cln_f2u(c[1]);
+        pixel[4 * id + 2] = (uint8_t)cln_f2u(c[2]);
+        pixel[4 * id + 3] = 255;
+    }
+}
+
+float oracle_bi_sin(float x) { return cln_sin(x); }
+float oracle_bi_cos(float x) { return cln_cos(x); }
