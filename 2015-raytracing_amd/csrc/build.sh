@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds libmirt.so (HIP kernels + C ABI) for gfx950, in-tree.  Cross-compiles without a GPU.
+#   -ffp-contract=off / no fast-math : part of the numerics contract (pt_numerics.hpp)
+#   -fhip-fp32-correctly-rounded-divide-sqrt : the hipcc default, spelled out because parity depends on it
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="${HERE}/../libmirt.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden
+       -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt
+       -Wall -Wextra -Wno-unused-parameter)
+"${HIPCC}" "${FLAGS[@]}" -shared -o "${OUT}" \
+    "${HERE}/mirt_abi.cpp" "${HERE}/pt_kernels_granular.hip" "${HERE}/pt_kernels_fused.hip" "$@"
+echo "built ${OUT}"

@@ -1,0 +1,712 @@
+// mirt_abi.cpp -- implementation of include/mirt.h: contexts, buffers, the WebCL-shaped
+// kernel objects (argument marshalling + launch validation) and the fused pass.
+//
+// Everything a launch will touch is checked on the host BEFORE the kernel is enqueued:
+// buffer extents against the work-item count, cell-offset tables for monotonicity and
+// extent, argument sizes.  A bad argument therefore comes back as an error code; it does
+// not become an out-of-bounds access on the GPU.
+#include "../../include/mirt.h"
+#include "pt_launch.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+constexpr size_t kRayBytes = 48, kPoiBytes = 64, kAcuBytes = 16;
+
+thread_local std::string t_last_error = "";
+
+std::mutex g_live_mu;
+std::unordered_set<const void*> g_live;
+
+void live_add(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.insert(p); }
+void live_del(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.erase(p); }
+bool live_has(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); return p && g_live.count(p) != 0; }
+
+}  // namespace
+
+struct mirt_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    void* scratch = nullptr;  // lens draws of the rpp==1 mode
+    size_t scratch_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profiling = false;       // per-kernel events inside mirt_render_pass
+    hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
+    bool pe_valid = false;
+};
+
+struct mirt_buf {
+    mirt_ctx* ctx = nullptr;
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    bool owned = true;
+    unsigned flags = 0;
+    uint64_t version = 1;  // bumped by every host write / device zero
+    // cell-offset validation cache
+    uint64_t off_version = 0;
+    uint32_t off_n = 0;
+    uint32_t off_last = 0;
+};
+
+enum ArgType { A_BUF, A_U32, A_F32, A_F16, A_AABB };
+enum KernelId {
+    K_sizeofRay, K_sizeofPoi, K_initAcu, K_initTrace, K_sphereTrace, K_triangleTrace, K_meshTrace, K_lightRender,
+    K_initShadowTrace, K_sphereShadowTrace, K_triangleShadowTrace, K_sceneRender, K_bouncePaths, K_copyToPixel, K_COUNT
+};
+
+struct KernelSpec { const char* name; KernelId id; std::vector<ArgType> args; };
+
+static const std::vector<KernelSpec>& kernel_table() {
+    // argument lists: A10 code.cl:440-1386 as bound by A10 code.js
+    static const std::vector<KernelSpec> t = {
+        {"sizeofRay", K_sizeofRay, {A_BUF}},
+        {"sizeofPoi", K_sizeofPoi, {A_BUF}},
+        {"initAcu", K_initAcu, {A_BUF, A_U32}},
+        {"initTrace", K_initTrace, {A_BUF, A_BUF, A_BUF, A_AABB, A_F16, A_F32, A_F32, A_U32}},
+        {"sphereTrace", K_sphereTrace, {A_U32, A_BUF, A_BUF, A_BUF, A_BUF, A_BUF, A_AABB, A_U32}},
+        {"triangleTrace", K_triangleTrace, {A_U32, A_BUF, A_BUF, A_BUF, A_BUF, A_BUF, A_BUF, A_AABB, A_U32}},
+        {"meshTrace", K_meshTrace, {A_U32, A_BUF, A_BUF, A_BUF, A_BUF, A_BUF, A_U32, A_AABB, A_U32}},
+        {"lightRender", K_lightRender, {A_BUF, A_BUF, A_BUF, A_F16, A_U32}},
+        {"initShadowTrace", K_initShadowTrace, {A_BUF, A_BUF, A_U32, A_F16, A_BUF}},
+        {"sphereShadowTrace", K_sphereShadowTrace, {A_U32, A_BUF, A_BUF, A_BUF, A_AABB, A_U32}},
+        {"triangleShadowTrace", K_triangleShadowTrace, {A_U32, A_BUF, A_BUF, A_BUF, A_AABB, A_U32}},
+        {"sceneRender", K_sceneRender, {A_BUF, A_BUF, A_BUF, A_BUF, A_F16, A_U32}},
+        {"bouncePaths", K_bouncePaths, {A_BUF, A_BUF, A_BUF, A_U32}},
+        {"copyToPixel", K_copyToPixel, {A_BUF, A_BUF, A_F32, A_U32, A_U32}},
+    };
+    return t;
+}
+
+struct KArg {
+    bool set = false;
+    mirt_buf* buf = nullptr;
+    union { uint32_t u; float f; float v[16]; } val;
+};
+
+struct mirt_kernel {
+    mirt_ctx* ctx = nullptr;
+    const KernelSpec* spec = nullptr;
+    std::vector<KArg> args;
+};
+
+namespace {
+
+int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    t_last_error = buf;
+    if (ctx && live_has(ctx)) ctx->last_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail((ctx), MIRT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+size_t arg_size(ArgType t) {
+    switch (t) {
+        case A_U32: case A_F32: return 4;
+        case A_F16: return 64;
+        case A_AABB: return 32;
+        default: return 0;
+    }
+}
+
+uint32_t f2u_host(float f) {
+    if (!(f == f)) return 0u;
+    if (f >= 4294967296.0f) return UINT32_MAX;
+    if (f <= 0.0f) return 0u;
+    return (uint32_t)f;
+}
+
+int need(mirt_ctx* ctx, const char* what, const mirt_buf* b, uint64_t bytes) {
+    if (!live_has(b)) return fail(ctx, MIRT_E_HANDLE, "%s: released or unknown buffer", what);
+    if (b->ctx != ctx) return fail(ctx, MIRT_E_ARG, "%s: buffer belongs to another context", what);
+    if ((uint64_t)b->bytes < bytes)
+        return fail(ctx, MIRT_E_RANGE, "%s: buffer holds %zu bytes, launch needs %llu", what, b->bytes, (unsigned long long)bytes);
+    return MIRT_OK;
+}
+
+// Checks a cell-offset table (uint[n^3+1], non-decreasing) and that the primitive arrays hold
+// off[n^3] entries.  The table is read back once per (buffer contents, n) and cached.
+int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const mirt_buf* prims, size_t prim_stride,
+               const mirt_buf* normals, const mirt_buf* matid) {
+    if (n == 0 || n > 1024) return fail(ctx, MIRT_E_ARG, "%s: n_slabs %u outside 1..1024", what, n);
+    const uint64_t cells = (uint64_t)n * n * n;
+    int rc = need(ctx, what, off, (cells + 1) * 4);
+    if (rc) return rc;
+    if (!(off->off_version == off->version && off->off_n == n)) {
+        std::vector<uint32_t> h(cells + 1);
+        HIPCHK(ctx, hipMemcpyAsync(h.data(), off->ptr, (cells + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint64_t i = 0; i < cells; ++i)
+            if (h[i] > h[i + 1]) return fail(ctx, MIRT_E_DATA, "%s: cell offsets decrease at cell %llu", what, (unsigned long long)i);
+        off->off_version = off->version;
+        off->off_n = n;
+        off->off_last = h[cells];
+    }
+    const uint64_t count = off->off_last;
+    rc = need(ctx, what, prims, count * prim_stride);
+    if (rc) return rc;
+    if (normals && (rc = need(ctx, what, normals, count * prim_stride))) return rc;
+    if (matid && (rc = need(ctx, what, matid, count * 4))) return rc;
+    return MIRT_OK;
+}
+
+int ensure_scratch(mirt_ctx* ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return MIRT_OK;
+    if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    HIPCHK(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return MIRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mirt_version(void) { return "mirt 0.1 (gfx950)"; }
+
+int mirt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int mirt_device_name(int device, char* out, size_t cap) {
+    if (!out || cap == 0) return fail(nullptr, MIRT_E_ARG, "mirt_device_name: null output");
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, MIRT_E_NODEVICE, "no HIP device %d", device); }
+    snprintf(out, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return MIRT_OK;
+}
+
+int mirt_ctx_create(int device, mirt_ctx** out) {
+    if (!out) return fail(nullptr, MIRT_E_ARG, "mirt_ctx_create: null out");
+    *out = nullptr;
+    int n = mirt_device_count();
+    if (n <= 0) return fail(nullptr, MIRT_E_NODEVICE, "no HIP device visible: libmirt needs an MI355X (gfx950); there is no CPU fallback");
+    if (device < 0 || device >= n) return fail(nullptr, MIRT_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t p;
+    HIPCHK(nullptr, hipGetDeviceProperties(&p, device));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MIRT_E_NODEVICE, "device %d is %s; libmirt carries gfx950 code objects only", device, p.gcnArchName);
+    HIPCHK(nullptr, hipSetDevice(device));
+    mirt_ctx* c = new mirt_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, MIRT_E_DEVICE, "hipStreamCreate failed"); }
+    c->stream = c->own_stream;
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    for (auto& e : c->pe) (void)hipEventCreate(&e);
+    live_add(c);
+    *out = c;
+    return MIRT_OK;
+}
+
+int mirt_ctx_destroy(mirt_ctx* ctx) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_destroy: unknown context");
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto& e : ctx->pe) if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    live_del(ctx);
+    delete ctx;
+    return MIRT_OK;
+}
+
+const char* mirt_last_error(mirt_ctx* ctx) {
+    if (ctx && live_has(ctx)) return ctx->last_error.c_str();
+    return t_last_error.c_str();
+}
+
+int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_stream: unknown context");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MIRT_OK;
+}
+
+int mirt_finish(mirt_ctx* ctx) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_finish: unknown context");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MIRT_OK;
+}
+
+int mirt_buf_create(mirt_ctx* ctx, size_t bytes, unsigned flags, mirt_buf** out) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_create: unknown context");
+    if (!out) return fail(ctx, MIRT_E_ARG, "mirt_buf_create: null out");
+    *out = nullptr;
+    if (bytes == 0) return fail(ctx, MIRT_E_ARG, "mirt_buf_create: zero-size buffer (WebCL INVALID_BUFFER_SIZE)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    HIPCHK(ctx, hipMalloc(&p, bytes));
+    mirt_buf* b = new mirt_buf();
+    b->ctx = ctx; b->ptr = p; b->bytes = bytes; b->owned = true; b->flags = flags;
+    live_add(b);
+    *out = b;
+    return MIRT_OK;
+}
+
+int mirt_buf_wrap(mirt_ctx* ctx, void* device_ptr, size_t bytes, mirt_buf** out) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_wrap: unknown context");
+    if (!out || !device_ptr || bytes == 0) return fail(ctx, MIRT_E_ARG, "mirt_buf_wrap: null pointer or zero size");
+    if (((uintptr_t)device_ptr & 15u) != 0) return fail(ctx, MIRT_E_ARG, "mirt_buf_wrap: device pointer must be 16-byte aligned");
+    mirt_buf* b = new mirt_buf();
+    b->ctx = ctx; b->ptr = device_ptr; b->bytes = bytes; b->owned = false; b->flags = MIRT_MEM_READ_WRITE;
+    live_add(b);
+    *out = b;
+    return MIRT_OK;
+}
+
+int mirt_buf_release(mirt_buf* buf) {
+    if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_release: unknown or already released buffer");
+    mirt_ctx* ctx = buf->ctx;
+    live_del(buf);
+    if (buf->owned && live_has(ctx)) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(buf->ptr);
+    }
+    delete buf;
+    return MIRT_OK;
+}
+
+size_t mirt_buf_size(const mirt_buf* buf) { return live_has(buf) ? buf->bytes : 0; }
+void* mirt_buf_device_ptr(const mirt_buf* buf) { return live_has(buf) ? buf->ptr : nullptr; }
+
+int mirt_buf_write(mirt_buf* buf, size_t offset, size_t nbytes, const void* host, int blocking) {
+    (void)blocking;
+    if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_write: unknown buffer");
+    mirt_ctx* ctx = buf->ctx;
+    if (!host && nbytes) return fail(ctx, MIRT_E_ARG, "mirt_buf_write: null host pointer");
+    if (offset > buf->bytes || nbytes > buf->bytes - offset)
+        return fail(ctx, MIRT_E_RANGE, "mirt_buf_write: [%zu, +%zu) exceeds buffer of %zu bytes", offset, nbytes, buf->bytes);
+    if (!nbytes) return MIRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync((char*)buf->ptr + offset, host, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the host array is borrowed for this call only
+    buf->version++;
+    return MIRT_OK;
+}
+
+int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* host, int blocking) {
+    (void)blocking;
+    if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_read: unknown buffer");
+    mirt_ctx* ctx = buf->ctx;
+    if (!host && nbytes) return fail(ctx, MIRT_E_ARG, "mirt_buf_read: null host pointer");
+    if (offset > buf->bytes || nbytes > buf->bytes - offset)
+        return fail(ctx, MIRT_E_RANGE, "mirt_buf_read: [%zu, +%zu) exceeds buffer of %zu bytes", offset, nbytes, buf->bytes);
+    if (!nbytes) return MIRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(host, (const char*)buf->ptr + offset, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return MIRT_OK;
+}
+
+int mirt_program_check(mirt_ctx* ctx, const char* source, char* missing, size_t cap) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_program_check: unknown context");
+    if (!source) return fail(ctx, MIRT_E_ARG, "mirt_program_check: null source");
+    std::string miss;
+    int n_missing = 0;
+    const char* p = source;
+    bool in_block_comment = false;
+    // scan for `__kernel void NAME (` outside comments
+    while (*p) {
+        if (in_block_comment) {
+            if (p[0] == '*' && p[1] == '/') { in_block_comment = false; p += 2; } else ++p;
+            continue;
+        }
+        if (p[0] == '/' && p[1] == '*') { in_block_comment = true; p += 2; continue; }
+        if (p[0] == '/' && p[1] == '/') { while (*p && *p != '\n') ++p; continue; }
+        if (strncmp(p, "__kernel", 8) == 0) {
+            const char* q = p + 8;
+            while (*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r') ++q;
+            if (strncmp(q, "void", 4) == 0) {
+                q += 4;
+                while (*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r') ++q;
+                const char* b = q;
+                while ((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || (*q >= '0' && *q <= '9') || *q == '_') ++q;
+                std::string name(b, q);
+                bool found = false;
+                for (const auto& s : kernel_table()) if (name == s.name) found = true;
+                if (!found && !name.empty()) { if (n_missing++) miss += ","; miss += name; }
+            }
+            p = q;
+            continue;
+        }
+        ++p;
+    }
+    if (missing && cap) { snprintf(missing, cap, "%s", miss.c_str()); }
+    return n_missing;
+}
+
+int mirt_kernel_get(mirt_ctx* ctx, const char* name, mirt_kernel** out) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_kernel_get: unknown context");
+    if (!name || !out) return fail(ctx, MIRT_E_ARG, "mirt_kernel_get: null argument");
+    *out = nullptr;
+    for (const auto& s : kernel_table()) {
+        if (strcmp(name, s.name) == 0) {
+            mirt_kernel* k = new mirt_kernel();
+            k->ctx = ctx; k->spec = &s; k->args.resize(s.args.size());
+            live_add(k);
+            *out = k;
+            return MIRT_OK;
+        }
+    }
+    return fail(ctx, MIRT_E_NAME, "no kernel named '%s' (INVALID_KERNEL_NAME)", name);
+}
+
+int mirt_kernel_release(mirt_kernel* k) {
+    if (!live_has(k)) return fail(nullptr, MIRT_E_HANDLE, "mirt_kernel_release: unknown or already released kernel");
+    live_del(k);
+    delete k;
+    return MIRT_OK;
+}
+
+int mirt_kernel_num_args(const mirt_kernel* k) { return live_has(k) ? (int)k->spec->args.size() : MIRT_E_HANDLE; }
+int mirt_kernel_preferred_multiple(const mirt_kernel* k) { return live_has(k) ? 64 : MIRT_E_HANDLE; }
+
+int mirt_kernel_set_arg(mirt_kernel* k, unsigned index, size_t size, const void* value) {
+    if (!live_has(k)) return fail(nullptr, MIRT_E_HANDLE, "mirt_kernel_set_arg: unknown kernel");
+    mirt_ctx* ctx = k->ctx;
+    if (index >= k->args.size()) return fail(ctx, MIRT_E_ARG, "%s: argument index %u out of range (%zu args)", k->spec->name, index, k->args.size());
+    ArgType t = k->spec->args[index];
+    if (t == A_BUF) return fail(ctx, MIRT_E_ARG, "%s: argument %u is a buffer; use mirt_kernel_set_arg_buf", k->spec->name, index);
+    if (!value || size != arg_size(t))
+        return fail(ctx, MIRT_E_ARG, "%s: argument %u expects %zu bytes, got %zu (INVALID_ARG_SIZE)", k->spec->name, index, arg_size(t), size);
+    memcpy(&k->args[index].val, value, size);
+    k->args[index].set = true;
+    return MIRT_OK;
+}
+
+int mirt_kernel_set_arg_buf(mirt_kernel* k, unsigned index, mirt_buf* buf) {
+    if (!live_has(k)) return fail(nullptr, MIRT_E_HANDLE, "mirt_kernel_set_arg_buf: unknown kernel");
+    mirt_ctx* ctx = k->ctx;
+    if (index >= k->args.size()) return fail(ctx, MIRT_E_ARG, "%s: argument index %u out of range", k->spec->name, index);
+    if (k->spec->args[index] != A_BUF) return fail(ctx, MIRT_E_ARG, "%s: argument %u is not a buffer", k->spec->name, index);
+    if (!live_has(buf)) return fail(ctx, MIRT_E_HANDLE, "%s: argument %u: unknown or released buffer", k->spec->name, index);
+    if (buf->ctx != ctx) return fail(ctx, MIRT_E_ARG, "%s: argument %u: buffer belongs to another context", k->spec->name, index);
+    k->args[index].buf = buf;
+    k->args[index].set = true;
+    return MIRT_OK;
+}
+
+int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* global, const size_t* local) {
+    (void)local;  // no kernel uses local memory or barriers: the work-group shape is ours to choose
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_enqueue: unknown context");
+    if (!live_has(k) || k->ctx != ctx) return fail(ctx, MIRT_E_HANDLE, "mirt_enqueue: unknown kernel");
+    const KernelSpec& S = *k->spec;
+    if (!global || dim < 1 || dim > 3) return fail(ctx, MIRT_E_ARG, "%s: bad NDRange", S.name);
+    for (size_t i = 0; i < k->args.size(); ++i) {
+        if (!k->args[i].set) return fail(ctx, MIRT_E_UNSET, "%s: argument %zu was never set (INVALID_KERNEL_ARGS)", S.name, i);
+        if (S.args[i] == A_BUF && !live_has(k->args[i].buf)) return fail(ctx, MIRT_E_HANDLE, "%s: argument %zu: buffer was released", S.name, i);
+    }
+    for (unsigned d = 0; d < dim; ++d)
+        if (global[d] > 0xFFFFFFFFull) return fail(ctx, MIRT_E_ARG, "%s: global size exceeds 2^32", S.name);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    auto& a = k->args;
+    const uint32_t g0 = (uint32_t)global[0];
+    int rc;
+#define BUF(i) (a[i].buf)
+#define U(i) (a[i].val.u)
+#define F(i) (a[i].val.f)
+#define V(i) (a[i].val.v)
+    switch (S.id) {
+        case K_sizeofRay:
+        case K_sizeofPoi:
+            if ((rc = need(ctx, S.name, BUF(0), 4))) return rc;
+            pt::launch_sizeof(st, S.id == K_sizeofRay, (uint32_t*)BUF(0)->ptr);
+            break;
+        case K_initAcu: {
+            uint32_t cnt = std::min(g0, U(1));
+            if ((rc = need(ctx, S.name, BUF(0), (uint64_t)cnt * kAcuBytes))) return rc;
+            pt::launch_initAcu(st, BUF(0)->ptr, U(1), g0);
+            BUF(0)->version++;
+            break;
+        }
+        case K_initTrace: {
+            if (dim != 2) return fail(ctx, MIRT_E_ARG, "initTrace is a 2-D NDRange (A10 code.js:1330)");
+            const uint32_t g1 = (uint32_t)global[1];
+            const uint32_t cols = f2u_host(V(4)[14]), rows = f2u_host(V(4)[15]);
+            const uint32_t rpp = U(7);
+            const uint32_t wc = std::min(g0, cols), wr = std::min(g1, rows);
+            if (wc && wr) {
+                if (rpp == 0) return fail(ctx, MIRT_E_ARG, "initTrace: rays_per_pixel is 0");
+                uint64_t rays = ((uint64_t)cols * (wr - 1) + wc) * rpp;  // one past the last ray touched
+                if ((rc = need(ctx, "initTrace rays", BUF(1), rays * kRayBytes))) return rc;
+                if ((rc = need(ctx, "initTrace pois", BUF(2), rays * kPoiBytes))) return rc;
+                if (rpp == 1) {
+                    if ((rc = need(ctx, "initTrace seeds", BUF(0), (uint64_t)wc * 4))) return rc;
+                    if ((rc = ensure_scratch(ctx, (size_t)cols * rows * 8))) return rc;
+                    pt::launch_lensDraws(st, BUF(0)->ptr, ctx->scratch, cols, rows, g0, g1, 0, rows);
+                }
+                pt::launch_initTrace(st, BUF(1)->ptr, BUF(2)->ptr, ctx->scratch, V(3), V(4), F(5), F(6), rpp, g0, g1);
+            }
+            break;
+        }
+        case K_sphereTrace: {
+            uint32_t cnt = std::min(g0, U(0));
+            if ((rc = need(ctx, "sphereTrace pois", BUF(1), (uint64_t)cnt * kPoiBytes))) return rc;
+            if ((rc = need(ctx, "sphereTrace rays", BUF(2), (uint64_t)cnt * kRayBytes))) return rc;
+            if ((rc = check_grid(ctx, "sphereTrace grid", BUF(5), U(7), BUF(3), 16, nullptr, BUF(4)))) return rc;
+            pt::launch_closest(st, pt::KIND_SPHERES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, nullptr, BUF(4)->ptr, 0, BUF(5)->ptr, V(6), U(7), g0);
+            break;
+        }
+        case K_triangleTrace: {
+            uint32_t cnt = std::min(g0, U(0));
+            if ((rc = need(ctx, "triangleTrace pois", BUF(1), (uint64_t)cnt * kPoiBytes))) return rc;
+            if ((rc = need(ctx, "triangleTrace rays", BUF(2), (uint64_t)cnt * kRayBytes))) return rc;
+            if ((rc = check_grid(ctx, "triangleTrace grid", BUF(6), U(8), BUF(3), 48, BUF(4), BUF(5)))) return rc;
+            pt::launch_closest(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, BUF(4)->ptr, BUF(5)->ptr, 0, BUF(6)->ptr, V(7), U(8), g0);
+            break;
+        }
+        case K_meshTrace: {
+            uint32_t cnt = std::min(g0, U(0));
+            if ((rc = need(ctx, "meshTrace pois", BUF(1), (uint64_t)cnt * kPoiBytes))) return rc;
+            if ((rc = need(ctx, "meshTrace rays", BUF(2), (uint64_t)cnt * kRayBytes))) return rc;
+            if ((rc = check_grid(ctx, "meshTrace grid", BUF(5), U(8), BUF(3), 48, BUF(4), nullptr))) return rc;
+            pt::launch_closest(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, BUF(4)->ptr, nullptr, U(6), BUF(5)->ptr, V(7), U(8), g0);
+            break;
+        }
+        case K_lightRender: {
+            uint32_t cnt = std::min(g0, U(4));
+            if ((rc = need(ctx, "lightRender pois", BUF(0), (uint64_t)cnt * kPoiBytes))) return rc;
+            if ((rc = need(ctx, "lightRender rays", BUF(1), (uint64_t)cnt * kRayBytes))) return rc;
+            if ((rc = need(ctx, "lightRender acu", BUF(2), (uint64_t)cnt * kAcuBytes))) return rc;
+            pt::launch_lightRender(st, BUF(0)->ptr, BUF(1)->ptr, BUF(2)->ptr, V(3), U(4), g0);
+            break;
+        }
+        case K_initShadowTrace: {
+            uint32_t cnt = std::min(g0, U(2));
+            if ((rc = need(ctx, "initShadowTrace shadow", BUF(0), (uint64_t)cnt * kRayBytes))) return rc;
+            if ((rc = need(ctx, "initShadowTrace pois", BUF(1), (uint64_t)cnt * kPoiBytes))) return rc;
+            if ((rc = need(ctx, "initShadowTrace seeds", BUF(4), (uint64_t)cnt * 4))) return rc;
+            pt::launch_initShadowTrace(st, BUF(0)->ptr, BUF(1)->ptr, U(2), V(3), BUF(4)->ptr, g0);
+            break;
+        }
+        case K_sphereShadowTrace: {
+            uint32_t cnt = std::min(g0, U(0));
+            if ((rc = need(ctx, "sphereShadowTrace shadow", BUF(1), (uint64_t)cnt * kRayBytes))) return rc;
+            if ((rc = check_grid(ctx, "sphereShadowTrace grid", BUF(3), U(5), BUF(2), 16, nullptr, nullptr))) return rc;
+            pt::launch_anyhit(st, pt::KIND_SPHERES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, V(4), U(5), g0);
+            break;
+        }
+        case K_triangleShadowTrace: {
+            uint32_t cnt = std::min(g0, U(0));
+            if ((rc = need(ctx, "triangleShadowTrace shadow", BUF(1), (uint64_t)cnt * kRayBytes))) return rc;
+            if ((rc = check_grid(ctx, "triangleShadowTrace grid", BUF(3), U(5), BUF(2), 48, nullptr, nullptr))) return rc;
+            pt::launch_anyhit(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, V(4), U(5), g0);
+            break;
+        }
+        case K_sceneRender: {
+            uint32_t cnt = std::min(g0, U(5));
+            if ((rc = need(ctx, "sceneRender acu", BUF(0), (uint64_t)cnt * kAcuBytes))) return rc;
+            if ((rc = need(ctx, "sceneRender pois", BUF(1), (uint64_t)cnt * kPoiBytes))) return rc;
+            if ((rc = need(ctx, "sceneRender shadow", BUF(2), (uint64_t)cnt * kRayBytes))) return rc;
+            pt::launch_sceneRender(st, BUF(0)->ptr, BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, (uint32_t)(BUF(3)->bytes / 16), V(4), U(5), g0);
+            break;
+        }
+        case K_bouncePaths: {
+            uint32_t cnt = std::min(g0, U(3));
+            if ((rc = need(ctx, "bouncePaths pois", BUF(0), (uint64_t)cnt * kPoiBytes))) return rc;
+            if ((rc = need(ctx, "bouncePaths rays", BUF(1), (uint64_t)cnt * kRayBytes))) return rc;
+            if ((rc = need(ctx, "bouncePaths seeds", BUF(2), (uint64_t)cnt * 4))) return rc;
+            pt::launch_bouncePaths(st, BUF(0)->ptr, BUF(1)->ptr, BUF(2)->ptr, U(3), g0);
+            break;
+        }
+        case K_copyToPixel: {
+            uint32_t cnt = std::min(g0, U(3));
+            if ((rc = need(ctx, "copyToPixel pixel", BUF(0), (uint64_t)cnt * 4))) return rc;
+            if ((rc = need(ctx, "copyToPixel acu", BUF(1), (uint64_t)cnt * U(4) * kAcuBytes))) return rc;
+            pt::launch_copyToPixel(st, BUF(0)->ptr, BUF(1)->ptr, F(2), U(3), U(4), g0, nullptr);
+            break;
+        }
+        default:
+            return fail(ctx, MIRT_E_NAME, "kernel not implemented");
+    }
+#undef BUF
+#undef U
+#undef F
+#undef V
+    HIPCHK(ctx, hipGetLastError());
+    return MIRT_OK;
+}
+
+static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool tri, bool per_prim_matid, pt::GridArgs* o) {
+    if (!g->prims || !g->cell_offsets) return fail(ctx, MIRT_E_ARG, "%s: null geometry buffer", what);
+    if (tri && !g->normals) return fail(ctx, MIRT_E_ARG, "%s: triangles need a normal buffer", what);
+    if (per_prim_matid && !g->matid) return fail(ctx, MIRT_E_ARG, "%s: needs a per-primitive material buffer", what);
+    int rc = check_grid(ctx, what, g->cell_offsets, g->n_slabs, g->prims, tri ? 48 : 16, tri ? g->normals : nullptr,
+                        per_prim_matid ? g->matid : nullptr);
+    if (rc) return rc;
+    o->prims = g->prims->ptr;
+    o->normals = tri ? g->normals->ptr : nullptr;
+    o->matid = per_prim_matid ? g->matid->ptr : nullptr;
+    o->off = g->cell_offsets->ptr;
+    memcpy(o->bound, g->bounds, sizeof o->bound);
+    o->n = g->n_slabs;
+    o->mesh_matid = g->mesh_matid;
+    return MIRT_OK;
+}
+
+int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_render_pass: unknown context");
+    if (!d || d->struct_size != sizeof(mirt_pass_desc)) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: descriptor size mismatch");
+    if (!d->width || !d->height || !d->rays_per_pixel) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: empty image");
+    if (d->n_lights > MIRT_MAX_LIGHTS) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: %u lights > %d (enqueue the kernels one by one instead)", d->n_lights, MIRT_MAX_LIGHTS);
+    if (d->n_meshes > MIRT_MAX_MESHES) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: %u meshes > %d (enqueue the kernels one by one instead)", d->n_meshes, MIRT_MAX_MESHES);
+    if ((d->n_lights && !d->lights) || (d->n_meshes && !d->meshes)) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: null light/mesh array");
+    if (!d->pass_index) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: pass_index is 1-based");
+    const uint32_t cols = f2u_host(d->cam[14]), rows = f2u_host(d->cam[15]);
+    if (cols != d->width || rows != d->height) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: camera says %ux%u, descriptor %ux%u", cols, rows, d->width, d->height);
+    const uint32_t nrows = d->nrows ? d->nrows : d->height;
+    if (d->row0 >= d->height || nrows > d->height - d->row0) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: row tile [%u,+%u) outside the image", d->row0, nrows);
+    const uint64_t npix = (uint64_t)nrows * d->width;
+    const uint64_t nrays = npix * d->rays_per_pixel;
+    if (nrays > 0xFFFFFFFFull) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: %llu rays in one tile; split the rows over more launches", (unsigned long long)nrays);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    pt::FusedArgs A;
+    memset(&A, 0, sizeof A);
+    memcpy(A.cam, d->cam, sizeof A.cam);
+    memcpy(A.bound, d->scene_bounds, sizeof A.bound);
+    A.focal_length = d->focal_length; A.lens_rad = d->lens_rad;
+    A.width = d->width; A.height = d->height; A.rpp = d->rays_per_pixel;
+    A.row0 = d->row0; A.nrows = nrows; A.bounces = d->bounces;
+    A.n_lights = d->n_lights; A.n_meshes = d->n_meshes;
+    int rc;
+    if (d->spheres) { A.has_spheres = 1; if ((rc = fill_grid(ctx, "spheres", d->spheres, false, true, &A.spheres))) return rc; }
+    if (d->triangles) { A.has_triangles = 1; if ((rc = fill_grid(ctx, "triangles", d->triangles, true, true, &A.triangles))) return rc; }
+    for (uint32_t m = 0; m < d->n_meshes; ++m)
+        if ((rc = fill_grid(ctx, "mesh", &d->meshes[m], true, false, &A.meshes[m]))) return rc;
+    for (uint32_t l = 0; l < d->n_lights; ++l) {
+        memcpy(A.lights[l].shadow, d->lights[l].shadow, 64);
+        memcpy(A.lights[l].scene, d->lights[l].scene, 64);
+        memcpy(A.lights[l].light, d->lights[l].light, 64);
+    }
+    if ((rc = need(ctx, "material", d->material, 16))) return rc;
+    A.material = d->material->ptr;
+    A.nmat = (uint32_t)(d->material->bytes / 16);
+    if ((rc = need(ctx, "seeds", d->seeds, nrays * 4))) return rc;
+    if ((rc = need(ctx, "acu", d->acu, nrays * kAcuBytes))) return rc;
+    A.seeds = (int32_t*)d->seeds->ptr;
+    A.acu = d->acu->ptr;
+    if (d->pixel && (rc = need(ctx, "pixel", d->pixel, npix * 4))) return rc;
+    if (d->radiance && (rc = need(ctx, "radiance", d->radiance, npix * 16))) return rc;
+
+    if (A.rpp == 1) {
+        // the column streams live in seeds[0..width): only the tile that owns row 0 holds them
+        if (d->row0 != 0) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: rays_per_pixel == 1 couples rows through seeds[col] (A10 code.cl:429); render it as one tile");
+        if ((rc = ensure_scratch(ctx, (size_t)npix * 8))) return rc;
+        pt::launch_lensDraws(ctx->stream, A.seeds, ctx->scratch, d->width, d->height, d->width, d->height, d->row0, nrows);
+        A.uv = ctx->scratch;
+    }
+    if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->pe[0], ctx->stream));
+    pt::launch_fused(ctx->stream, A);
+    if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->pe[1], ctx->stream));
+    if (d->pixel || d->radiance) {
+        const float m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
+        pt::launch_copyToPixel(ctx->stream, d->pixel ? d->pixel->ptr : nullptr, A.acu, m, (uint32_t)npix, A.rpp, (uint32_t)npix,
+                               d->radiance ? d->radiance->ptr : nullptr);
+    }
+    if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->pe[2], ctx->stream)); ctx->pe_valid = true; }
+    HIPCHK(ctx, hipGetLastError());
+    d->seeds->version++;
+    d->acu->version++;
+    return MIRT_OK;
+}
+
+int mirt_ctx_set_profiling(mirt_ctx* ctx, int on) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_profiling: unknown context");
+    ctx->profiling = on != 0;
+    ctx->pe_valid = false;
+    return MIRT_OK;
+}
+
+int mirt_pass_timing(mirt_ctx* ctx, float* fused_ms, float* resolve_ms) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_pass_timing: unknown context");
+    if (!ctx->pe_valid) return fail(ctx, MIRT_E_ARG, "mirt_pass_timing: no profiled mirt_render_pass yet (mirt_ctx_set_profiling)");
+    HIPCHK(ctx, hipEventSynchronize(ctx->pe[2]));
+    float a = 0.f, b = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&a, ctx->pe[0], ctx->pe[1]));
+    HIPCHK(ctx, hipEventElapsedTime(&b, ctx->pe[1], ctx->pe[2]));
+    if (fused_ms) *fused_ms = a;
+    if (resolve_ms) *resolve_ms = b;
+    return MIRT_OK;
+}
+
+int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, uint64_t count, uint32_t seed_base) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_seed_fill: unknown context");
+    int rc = need(ctx, "mirt_seed_fill", seeds, count * 4);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pt::launch_seedFill(ctx->stream, seeds->ptr, first_ray, count, seed_base);
+    HIPCHK(ctx, hipGetLastError());
+    seeds->version++;
+    return MIRT_OK;
+}
+
+int mirt_zero(mirt_ctx* ctx, mirt_buf* buf) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_zero: unknown context");
+    int rc = need(ctx, "mirt_zero", buf, 0);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(buf->ptr, 0, buf->bytes, ctx->stream));
+    buf->version++;
+    return MIRT_OK;
+}
+
+int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_numerics: unknown context");
+    int rc;
+    if ((rc = need(ctx, "mirt_debug_numerics a", a, (uint64_t)n * 4))) return rc;
+    if (b && (rc = need(ctx, "mirt_debug_numerics b", b, (uint64_t)n * 4))) return rc;
+    if ((rc = need(ctx, "mirt_debug_numerics out", out, (uint64_t)n * 4))) return rc;
+    if (op < 0 || op > 13) return fail(ctx, MIRT_E_ARG, "mirt_debug_numerics: op %d outside 0..13", op);
+    if (!b && (op == 0 || (op >= 6 && op <= 12))) return fail(ctx, MIRT_E_ARG, "mirt_debug_numerics: op %d needs two inputs", op);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pt::launch_numerics(ctx->stream, op, a->ptr, b ? b->ptr : nullptr, out->ptr, n);
+    HIPCHK(ctx, hipGetLastError());
+    return MIRT_OK;
+}
+
+int mirt_timer_start(mirt_ctx* ctx) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_timer_start: unknown context");
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return MIRT_OK;
+}
+
+int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_timer_stop_ms: unknown context");
+    if (!ms) return fail(ctx, MIRT_E_ARG, "mirt_timer_stop_ms: null output");
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return MIRT_OK;
+}
+
+}  // extern "C"

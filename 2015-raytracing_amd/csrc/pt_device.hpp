@@ -1,0 +1,388 @@
+// pt_device.hpp -- device building blocks of the Assign10 path (gfx950).
+//
+// One source of truth for the geometry used by both kernel families:
+//   * the reference-shaped granular kernels (pt_kernels_granular.hip), drop-in
+//     for the fourteen `__kernel`s of A10 code.cl behind the WebCL-shaped API;
+//   * the fused per-ray pass kernel (pt_kernels_fused.hip).
+// "A10 code.cl:NNN" cites the reference lines whose behaviour a block reproduces.
+// Evaluation order is part of the contract (pt_numerics.hpp): every expression is
+// spelled in the order OpenCL C evaluates the reference's, never contracted.
+#pragma once
+#include "pt_numerics.hpp"
+
+namespace pt {
+
+struct f3 { float x, y, z; };
+
+PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 scl3(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+PT_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PT_DEV float dot3(f3 a, f3 b) {
+    float s = a.x * b.x;
+    s = s + a.y * b.y;
+    s = s + a.z * b.z;
+    return s;
+}
+PT_DEV f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+PT_DEV float len3(f3 a) { return cl_sqrt(dot3(a, a)); }
+PT_DEV f3 norm3(f3 a) {
+    float inv = 1.0f / cl_sqrt(dot3(a, a));
+    return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
+PT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+PT_DEV f3 ld3(const float4& v) { return mk3(v.x, v.y, v.z); }
+
+#define PT_INF (__builtin_inff())
+#define PT_PI_4 0.785398163397448309616f
+#define PT_PI_2 1.57079632679489661923f
+
+// ---- AoS layouts of the reference interface (measured from the compiled reference:
+// Ray 48 B, Poi 64 B) ------------------------------------------
+struct alignas(16) RayAoS { float ox, oy, oz, _p0, dx, dy, dz, _p1, mint, maxt, _p2, _p3; };
+struct alignas(16) PoiAoS { float px, py, pz, _p0, nx, ny, nz, _p1, ax, ay, az, _p2; int32_t matId; int32_t _p3[3]; };
+static_assert(sizeof(RayAoS) == 48 && sizeof(PoiAoS) == 64, "reference struct sizes");
+
+struct Ray { f3 o, d; float mint, maxt; };
+struct Box { f3 lo, hi; };                  // AABB, host packing (min,1,max,1): A10 code.js:610-621
+struct Cam { f3 eye, U, V, W; float width, height; uint32_t cols, rows; };
+
+struct Box8 { float v[8]; };                // by-value kernel arguments
+struct F16 { float v[16]; };
+
+PT_DEV Box mk_box(const Box8& b) { Box r; r.lo = ld3(b.v); r.hi = ld3(b.v + 4); return r; }
+// A10 code.cl:73-84
+PT_DEV Cam mk_cam(const F16& f) {
+    Cam c;
+    c.eye = ld3(f.v); c.U = ld3(f.v + 3); c.V = ld3(f.v + 6); c.W = ld3(f.v + 9);
+    c.width = f.v[12]; c.height = f.v[13];
+    c.cols = f2u(f.v[14]); c.rows = f2u(f.v[15]);
+    return c;
+}
+
+// ---- RNG: A10 code.cl:420-434 --------------------------------------------------------
+// seed' = ((long)(int32)(seed*16807)) % (2^31-1): int32 wrap first, then C's truncating
+// remainder.  For an int32 x, x % (2^31-1) is x itself except at three values.
+PT_DEV int32_t lcg_next(int32_t s) {
+    int32_t w = (int32_t)((uint32_t)s * 16807u);
+    int32_t r = w;
+    r = (w == INT32_MAX) ? 0 : r;
+    r = (w == -INT32_MAX) ? 0 : r;
+    r = (w == INT32_MIN) ? -1 : r;
+    return r;
+}
+PT_DEV float lcg_float(int32_t s) { return cl_fabs((float)s * 4.656612873077392578125e-10f); }  // * 2^-31
+PT_DEV float get_rand(int32_t& seed) { seed = lcg_next(seed); return lcg_float(seed); }
+
+// ---- camera: A10 code.cl:108-119, 143-197 ------------------------------------------
+PT_DEV void concentric(float inx, float iny, float& ox, float& oy) {
+    if (inx == 0.0f && iny == 0.0f) { ox = inx; oy = iny; return; }
+    float a = (2.0f * inx) - 1.0f;
+    float b = (2.0f * iny) - 1.0f;
+    const bool top = (a * a) > (b * b);
+    float radius = top ? (1.0f * a) : (1.0f * b);
+    float q = top ? (b / a) : (a / b);
+    float pq = PT_PI_4 * q;
+    float phi = top ? pq : (PT_PI_2 - pq);
+    float s, c;
+    cl_sincos(phi, s, c);
+    ox = c * radius;
+    oy = s * radius;
+}
+
+PT_DEV f3 focal_point(const Cam& c, float col, float row, float focal_length) {
+    float sx = (-0.5f + (col + 0.5f) / (float)c.cols) * c.width;
+    float sy = (0.5f - (row + 0.5f) / (float)c.rows) * c.height;
+    f3 cop = add3(add3(scl3(sx, c.U), scl3(sy, c.V)), scl3(-1.0f, c.W));
+    f3 d = norm3(cop);
+    f3 o = c.eye;
+    f3 pip = add3(c.eye, scl3(-1.0f, scl3(focal_length, c.W)));
+    float pd = -dot3(pip, c.W);
+    float t = -(dot3(o, c.W) + pd) / dot3(d, c.W);
+    return add3(o, scl3(t, d));
+}
+
+PT_DEV Ray thin_lens_ray(const Cam& c, f3 fp, float lens_rad, float cx, float cy) {
+    Ray r;
+    float dx, dy;
+    concentric(cx, cy, dx, dy);
+    dx = dx * lens_rad;
+    dy = dy * lens_rad;
+    r.o = add3(add3(c.eye, scl3(dx, c.U)), scl3(dy, c.V));
+    r.d = norm3(sub3(fp, r.o));
+    r.mint = 0.0f;
+    r.maxt = PT_INF;
+    return r;
+}
+
+// ---- ray / box: A10 code.cl:335-389 ---------------------------------------------------
+struct BoxHit { float tmin, tmax; bool v; };
+
+PT_DEV bool slab1(float lo, float hi, float o, float d, BoxHit& h) {
+    float t0 = (lo - o) / d;
+    float t1 = (hi - o) / d;
+    const bool neg = d < 0;
+    float tn = neg ? t1 : t0;
+    float tf = neg ? t0 : t1;
+    h.tmin = cl_max(tn, h.tmin);
+    h.tmax = cl_min(tf, h.tmax);
+    return !(h.tmin > h.tmax);
+}
+PT_DEV BoxHit inter_aabb(const Ray& r, const Box& b) {
+    BoxHit h;
+    h.tmin = 0.0f;
+    h.tmax = PT_INF;
+    h.v = false;
+    if (!slab1(b.lo.x, b.hi.x, r.o.x, r.d.x, h)) return h;
+    if (!slab1(b.lo.y, b.hi.y, r.o.y, r.d.y, h)) return h;
+    if (!slab1(b.lo.z, b.hi.z, r.o.z, r.d.z, h)) return h;
+    h.v = true;
+    return h;
+}
+// primary-ray clip of initTrace (code.cl:494-501): miss -> mint = maxt ("dead ray")
+PT_DEV void clip_to(Ray& r, const Box& b) {
+    BoxHit h = inter_aabb(r, b);
+    if (h.v) { r.mint = h.tmin; r.maxt = h.tmax; }
+    else { r.mint = r.maxt; }
+}
+
+// ---- primitives ------------------------------------------------------------------------
+// code.cl:199-242; .w holds r^2 (host pushes rad*rad, A10 code.js:1602)
+PT_DEV bool inter_sphere(f3 o, f3 d, float mint, float maxt, const float4 sph, float& t_out) {
+    f3 omc = sub3(o, ld3(sph));
+    float a = dot3(d, d);
+    float b = 2.0f * dot3(omc, d);
+    float c = dot3(omc, omc) - sph.w;
+    float dis = cl_mad(-4.0f * c, a, b * b);
+    if (dis < 0.0f) return false;
+    a = 1.0f / (2.0f * a);
+    dis = cl_sqrt(dis);
+    float t0 = (-b - dis) * a;
+    float t1 = (-b + dis) * a;
+    float tmin = cl_fmin(t0, t1);
+    float tmax = cl_fmax(t0, t1);
+    if (tmin >= mint && tmin <= maxt) { t_out = tmin; return true; }
+    if (tmax >= mint && tmax <= maxt) { t_out = tmax; return true; }
+    return false;
+}
+
+// code.cl:250-288: Moeller-Trumbore, single-sided (div <= 0 rejects), closed t interval
+PT_DEV bool inter_triangle(f3 o, f3 d, float mint, float maxt, f3 p0, f3 p1, f3 p2,
+                           float& t_out, float& beta_out, float& gamma_out) {
+    f3 e1 = sub3(p1, p0);
+    f3 e2 = sub3(p2, p0);
+    float div = dot3(cross3(e2, e1), d);
+    if (div <= 0) return false;
+    float idiv = 1.0f / div;
+    f3 s = sub3(o, p0);
+    float beta = dot3(cross3(s, d), e2) * idiv;
+    if (beta < 0.0f || beta > 1.0f) return false;
+    float gamma = dot3(cross3(s, e1), d) * idiv;
+    float gb = gamma + beta;
+    if (gamma < 0.0f || gb < 0.0f || gb > 1.0f) return false;
+    float t = dot3(cross3(s, e2), e1) * -idiv;
+    if (t >= mint && t <= maxt) { t_out = t; beta_out = beta; gamma_out = gamma; return true; }
+    return false;
+}
+
+// ---- 3-D uniform grid, 3-axis DDA: the traversal the reference repeats at
+// A10 code.cl:694-786, 822-919, 957-1054, 1090-1183, 1213-1310 -------------------------
+struct Axis { int slab, dslab, limit; float dt, tnext; };
+
+PT_DEV Axis axis_setup(float o, float d, float tmin, float lo, float hi, uint32_t n) {
+    Axis a;
+    float x = o + tmin * d;
+    float delta = (hi - lo) / (float)n;
+    a.slab = f2i((x - lo) / delta);
+    if (a.slab < 0) a.slab = 0;
+    if ((uint32_t)a.slab >= n) a.slab = (int)(n - 1u);
+    const bool fwd = d >= 0;
+    a.dslab = fwd ? 1 : -1;
+    a.limit = fwd ? (int)n : -1;
+    a.dt = delta / cl_fabs(d);
+    float xnext = lo + (float)(a.slab + (fwd ? 1 : 0)) * delta;
+    a.tnext = (xnext - o) / d;
+    return a;
+}
+
+struct Champ { uint32_t idx; float t, beta, gamma; };
+
+enum PrimKind { SPHERES = 0, TRIANGLES = 1 };
+
+// A grid of one primitive kind as the reference uploads it: cell-sorted primitives with
+// duplication, `off[n^3+1]` prefix offsets, cell c = z*n*n + y*n + x.
+struct Grid {
+    const float4* prims;      // spheres: 1 float4 (c, r^2); triangles: 3 float4 (p0,p1,p2; w unused)
+    const uint32_t* off;
+    Box bound;
+    uint32_t n;
+};
+
+// Front-to-back walk; stops at the first cell that yields a hit (code.cl:766, 899).
+// ANY: leave the cell scan at the first accepted primitive (shadow kernels, code.cl:1159, 1286).
+template <int KIND, bool ANY>
+PT_DEV Champ grid_trace(const Ray& ray, const BoxHit& bh, const Grid& g) {
+    Axis ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, g.bound.lo.x, g.bound.hi.x, g.n);
+    Axis ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, g.bound.lo.y, g.bound.hi.y, g.n);
+    Axis az = axis_setup(ray.o.z, ray.d.z, bh.tmin, g.bound.lo.z, g.bound.hi.z, g.n);
+    Champ ch;
+    ch.idx = UINT32_MAX;
+    ch.t = ray.maxt;
+    ch.beta = 0.0f;
+    ch.gamma = 0.0f;
+    float t = bh.tmin;
+    const uint32_t zs = g.n * g.n, ys = g.n;
+    for (;;) {
+        const float cmin = t;
+        const float cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+        const uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
+        const uint32_t begin = g.off[cell], end = g.off[cell + 1];
+        for (uint32_t i = begin; i < end; ++i) {
+            float ti, b = 0.0f, gm = 0.0f;
+            bool hit;
+            if (KIND == SPHERES) {
+                hit = inter_sphere(ray.o, ray.d, cmin, cmax, g.prims[i], ti);
+            } else {
+                const float4* tp = g.prims + 3u * (size_t)i;
+                hit = inter_triangle(ray.o, ray.d, cmin, cmax, ld3(tp[0]), ld3(tp[1]), ld3(tp[2]), ti, b, gm);
+            }
+            if (hit && ti < ch.t) {
+                ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm;
+                if (ANY) break;
+            }
+        }
+        if (ch.idx != UINT32_MAX) break;
+        t = cmax;
+        if (t == ax.tnext) {
+            ax.tnext += ax.dt;
+            if (t >= bh.tmax) break;
+            ax.slab += ax.dslab;
+            if (ax.slab == ax.limit) break;
+        } else if (t == ay.tnext) {
+            ay.tnext += ay.dt;
+            if (t >= bh.tmax) break;
+            ay.slab += ay.dslab;
+            if (ay.slab == ay.limit) break;
+        } else {
+            az.tnext += az.dt;
+            if (t >= bh.tmax) break;
+            az.slab += az.dslab;
+            if (az.slab == az.limit) break;
+        }
+    }
+    return ch;
+}
+
+// A path vertex ("point of intersection"), code.cl:57-62
+struct Poi { f3 p, n, atte; int32_t matId; };
+
+// closest hit of one primitive set, z-buffered through ray.maxt (code.cl:675-800, 802-935,
+// 937-1070).  Writes p, normal, matId on a hit -- never atte (SURVEY 8a hazard 2); on a miss
+// the previous vertex stays live (hazard 3).
+template <int KIND>
+PT_DEV bool closest_hit(Ray& ray, Poi& poi, const Grid& g, const float4* normals,
+                        const uint32_t* matid, uint32_t mesh_matid) {
+    if (ray.mint == ray.maxt) return false;
+    BoxHit bh = inter_aabb(ray, g.bound);
+    if (!bh.v) return false;
+    Champ ch = grid_trace<KIND, false>(ray, bh, g);
+    if (ch.idx == UINT32_MAX) return false;
+    ray.maxt = ch.t;
+    poi.p = add3(ray.o, scl3(ch.t, ray.d));
+    if (KIND == SPHERES) {
+        poi.n = norm3(sub3(poi.p, ld3(g.prims[ch.idx])));
+    } else {
+        const float4* nn = normals + 3u * (size_t)ch.idx;
+        float w = 1.0f - ch.beta - ch.gamma;                         // code.cl:409-411
+        poi.n = norm3(add3(add3(scl3(w, ld3(nn[0])), scl3(ch.beta, ld3(nn[1]))), scl3(ch.gamma, ld3(nn[2]))));
+    }
+    poi.matId = (int32_t)(matid ? matid[ch.idx] : mesh_matid);
+    return true;
+}
+
+// any-hit of one primitive set for a shadow ray (code.cl:1073-1193, 1195-1321):
+// blocked -> mint = maxt = t (the "dead ray" mark the next kernels and sceneRender test).
+template <int KIND>
+PT_DEV void any_hit(Ray& sh, const Grid& g) {
+    if (sh.mint == sh.maxt) return;
+    BoxHit bh = inter_aabb(sh, g.bound);
+    if (!bh.v) return;
+    Champ ch = grid_trace<KIND, true>(sh, bh, g);
+    sh.maxt = ch.t;
+    if (ch.idx != UINT32_MAX) sh.mint = ch.t;
+}
+
+// ---- lights ------------------------------------------------------------------------------
+// code.cl:391-403 + 600-629.  Returns true when the disk emitter is seen before the surface.
+PT_DEV bool light_visible(const Ray& ray, f3 lpos, f3 lnor, float radius) {
+    float den = dot3(ray.d, lnor);
+    if (den == 0.0f) return false;
+    float num = dot3(sub3(lpos, ray.o), lnor);
+    if (num == 0.0f) return false;
+    float t = num / den;
+    f3 p = add3(ray.o, scl3(t, ray.d));
+    if (len3(sub3(p, lpos)) > radius) return false;
+    return !(t >= ray.maxt);
+}
+
+// code.cl:121-129 + 631-673: offset origin, concentric sample on the disk light, ray to it
+PT_DEV Ray shadow_ray(const Poi& poi, f3 lpos0, f3 T, f3 B, float radius, int32_t& seed) {
+    f3 p = add3(poi.p, scl3(0.001f, poi.n));
+    float x = get_rand(seed);
+    float y = get_rand(seed);
+    concentric(x, y, x, y);
+    x = x * radius;
+    y = y * radius;
+    f3 lpos = add3(lpos0, add3(scl3(x, T), scl3(y, B)));
+    f3 to = sub3(lpos, p);
+    Ray r;
+    r.o = p;
+    r.d = norm3(to);
+    r.mint = 0.0f;
+    r.maxt = len3(to);
+    return r;
+}
+
+// code.cl:1323-1364 minus the memory traffic: returns material*atte*shade and scales atte
+PT_DEV f3 shade_vertex(Poi& poi, const Ray& sh, f3 color, f3 lpos, f3 lnor, f3 es, float area) {
+    f3 shade = mk3(0.0f, 0.0f, 0.0f);
+    if (sh.maxt != sh.mint) {
+        float r = len3(sub3(poi.p, lpos));
+        float cosx = cl_clamp(dot3(sh.d, poi.n), 0.0f, 1.0f);
+        float cosy = cl_clamp(dot3(neg3(sh.d), lnor), 0.0f, 1.0f);
+        shade = scl3(area * ((cosx * cosy) / (r * r)), es);
+    }
+    f3 atte = poi.atte;
+    poi.atte = mul3(atte, color);
+    return mul3(mul3(color, atte), shade);
+}
+
+// code.cl:545-579: cosine-ish hemisphere direction about the vertex normal
+PT_DEV Ray bounce_ray(const Poi& poi, int32_t& seed) {
+    f3 N = mk3(cl_fabs(poi.n.x), cl_fabs(poi.n.y), cl_fabs(poi.n.z));
+    f3 B = poi.n;
+    float nmin = cl_min(cl_min(N.x, N.y), N.z);
+    if (N.x == nmin) B.x = 1.0f;
+    else if (N.y == nmin) B.y = 1.0f;
+    else B.z = 1.0f;
+    N = poi.n;
+    B = norm3(B);
+    f3 T = cross3(B, N);
+    B = cross3(N, T);
+    float sx = get_rand(seed);
+    float sy = get_rand(seed);
+    concentric(sx, sy, sx, sy);
+    float sz = cl_sqrt(cl_max(0.0f, 1.0f - sx * sx - sy * sy));
+    Ray r;
+    r.o = poi.p;
+    r.d = norm3(add3(add3(scl3(sx, T), scl3(sy, B)), scl3(sz, N)));
+    r.mint = 0.0f;
+    r.maxt = PT_INF;
+    return r;
+}
+
+}  // namespace pt

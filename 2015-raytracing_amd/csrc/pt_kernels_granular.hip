@@ -1,0 +1,348 @@
+// pt_kernels_granular.hip -- the fourteen kernels of A10 code.cl as HIP kernels for gfx950,
+// same names, same argument lists, same buffer layouts (AoS Ray 48 B / Poi 64 B), so that
+// the reference's own host code can drive them through the WebCL-shaped boundary
+// (include/mirt.h).  One work-item per ray (or per pixel for initTrace / copyToPixel).
+// These are HBM-bound by construction (every stage round-trips the ray state through
+// memory, ~4.2 KB/sample on cornell.xml); the fast path is pt_kernels_fused.hip.
+#include "pt_device.hpp"
+#include "pt_launch.hpp"
+
+namespace pt {
+
+PT_DEV Ray load_ray(const RayAoS* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float4 a = q[0], b = q[1];
+    float2 c = *reinterpret_cast<const float2*>(q + 2);
+    Ray r;
+    r.o = mk3(a.x, a.y, a.z);
+    r.d = mk3(b.x, b.y, b.z);
+    r.mint = c.x;
+    r.maxt = c.y;
+    return r;
+}
+PT_DEV void store_ray(RayAoS* p, const Ray& r) {
+    float4* q = reinterpret_cast<float4*>(p);
+    q[0] = make_float4(r.o.x, r.o.y, r.o.z, 0.0f);
+    q[1] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
+    *reinterpret_cast<float2*>(q + 2) = make_float2(r.mint, r.maxt);
+}
+PT_DEV void store_dead(RayAoS* p) {  // code.cl:595, 647: only mint/maxt are defined
+    *reinterpret_cast<float2*>(reinterpret_cast<float4*>(p) + 2) = make_float2(PT_INF, PT_INF);
+}
+
+// code.cl:440-446
+__global__ void k_sizeofRay(uint32_t* out) { if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (uint32_t)sizeof(RayAoS); }
+__global__ void k_sizeofPoi(uint32_t* out) { if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (uint32_t)sizeof(PoiAoS); }
+
+// code.cl:448-456
+__global__ void __launch_bounds__(256) k_initAcu(float4* acu, uint32_t total, uint32_t gsz) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= gsz || id >= total) return;
+    acu[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// rpp == 1 only.  The reference draws the two lens coordinates from seeds[get_global_id(0)]
+// inside a 2-D launch (code.cl:429 vs 469-470, 513-515): every row of a column shares one
+// stream, and the order is a data race on any parallel device.  The oracle's definition
+// (work-items in row-major order) makes row r of column c consume draws 2r+1, 2r+2; this
+// pre-pass walks each column's stream serially, one thread per column, and leaves the
+// coordinates in `uv` for k_initTrace.
+__global__ void __launch_bounds__(64) k_lensDraws(int32_t* seeds, float2* uv, uint32_t cols, uint32_t rows,
+                                                   uint32_t gx, uint32_t gy, uint32_t row0, uint32_t nrows) {
+    uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols || col >= gx) return;
+    int32_t s = seeds[col];
+    uint32_t rmax = rows < gy ? rows : gy;
+    for (uint32_t row = 0; row < rmax; ++row) {
+        float cy = get_rand(s);
+        float cx = get_rand(s);
+        if (row >= row0 && row < row0 + nrows) uv[(size_t)(row - row0) * cols + col] = make_float2(cx, cy);
+    }
+    seeds[col] = s;
+}
+
+// code.cl:458-543.  One work-item per pixel, rays_per_pixel rays each.
+__global__ void __launch_bounds__(256) k_initTrace(RayAoS* rays, PoiAoS* pois, const float2* uv, Box8 bound8, F16 cam16,
+                                                    float focal_length, float lens_rad, uint32_t rpp, uint32_t gx, uint32_t gy) {
+    const Cam cam = mk_cam(cam16);
+    const Box bound = mk_box(bound8);
+    uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t row = blockIdx.y * blockDim.y + threadIdx.y;
+    if (col >= gx || row >= gy) return;
+    if (col >= cam.cols || row >= cam.rows) return;
+    size_t base = ((size_t)cam.cols * row + col) * rpp;
+    f3 fp = focal_point(cam, (float)col, (float)row, focal_length);
+    if (rpp > 1) {
+        uint32_t side = f2u(cl_sqrt((float)rpp));
+        float delta = 1.0f / (float)side;
+        float cy = delta / 2.0f;
+        for (uint32_t i = 0; i < side; ++i) {
+            float cx = delta / 2.0f;
+            for (uint32_t j = 0; j < side; ++j) {
+                Ray r = thin_lens_ray(cam, fp, lens_rad, cx, cy);
+                clip_to(r, bound);
+                store_ray(&rays[base + (size_t)i * side + j], r);
+                cx += delta;
+            }
+            cy += delta;
+        }
+    } else {
+        float2 c = uv[(size_t)row * cam.cols + col];
+        Ray r = thin_lens_ray(cam, fp, lens_rad, c.x, c.y);
+        clip_to(r, bound);
+        store_ray(&rays[base], r);
+    }
+    for (uint32_t i = 0; i < rpp; ++i) {
+        PoiAoS* p = &pois[base + i];
+        p->ax = 1.0f; p->ay = 1.0f; p->az = 1.0f;
+        p->matId = -1;
+    }
+}
+
+// code.cl:581-598
+__global__ void __launch_bounds__(256) k_bouncePaths(const PoiAoS* pois, RayAoS* rays, int32_t* seeds, uint32_t total, uint32_t gsz) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= gsz || id >= total) return;
+    const PoiAoS* pp = &pois[id];
+    if (pp->matId >= 0) {
+        Poi poi;
+        poi.p = mk3(pp->px, pp->py, pp->pz);
+        poi.n = mk3(pp->nx, pp->ny, pp->nz);
+        int32_t s = seeds[id];
+        Ray r = bounce_ray(poi, s);
+        seeds[id] = s;
+        store_ray(&rays[id], r);
+    } else {
+        store_dead(&rays[id]);
+    }
+}
+
+// code.cl:600-629
+__global__ void __launch_bounds__(256) k_lightRender(PoiAoS* pois, RayAoS* rays, float4* acu, F16 light, uint32_t total, uint32_t gsz) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= gsz || id >= total) return;
+    Ray ray = load_ray(&rays[id]);
+    if (ray.mint == ray.maxt) return;
+    f3 irr = norm3(ld3(light.v + 6));
+    if (!light_visible(ray, ld3(light.v), ld3(light.v + 3), light.v[9])) return;
+    store_dead(&rays[id]);
+    pois[id].matId = -1;
+    float4 a = acu[id];
+    a.x += irr.x; a.y += irr.y; a.z += irr.z; a.w += 1.0f;
+    acu[id] = a;
+}
+
+// code.cl:631-673
+__global__ void __launch_bounds__(256) k_initShadowTrace(RayAoS* shadow, const PoiAoS* pois, uint32_t total, F16 light,
+                                                          int32_t* seeds, uint32_t gsz) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= gsz || id >= total) return;
+    const PoiAoS* pp = &pois[id];
+    if (pp->matId < 0) { store_dead(&shadow[id]); return; }
+    Poi poi;
+    poi.p = mk3(pp->px, pp->py, pp->pz);
+    poi.n = mk3(pp->nx, pp->ny, pp->nz);
+    int32_t s = seeds[id];
+    Ray r = shadow_ray(poi, ld3(light.v), ld3(light.v + 3), ld3(light.v + 6), light.v[9], s);
+    seeds[id] = s;
+    store_ray(&shadow[id], r);
+}
+
+// code.cl:675-800 (spheres), 802-935 (triangles, per-primitive material), 937-1070 (mesh,
+// one material): one template, three instantiations.
+template <int KIND>
+__global__ void __launch_bounds__(256) k_closest(uint32_t total, PoiAoS* pois, RayAoS* rays, const float4* prims,
+                                                  const float4* normals, const uint32_t* matid, uint32_t mesh_matid,
+                                                  const uint32_t* off, Box8 bound8, uint32_t n, uint32_t gsz) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= gsz || id >= total) return;
+    Ray ray = load_ray(&rays[id]);
+    Grid g;
+    g.prims = prims; g.off = off; g.bound = mk_box(bound8); g.n = n;
+    Poi poi;
+    if (!closest_hit<KIND>(ray, poi, g, normals, matid, mesh_matid)) return;
+    rays[id].maxt = ray.maxt;
+    PoiAoS* pp = &pois[id];
+    float4* q = reinterpret_cast<float4*>(pp);
+    q[0] = make_float4(poi.p.x, poi.p.y, poi.p.z, 0.0f);
+    q[1] = make_float4(poi.n.x, poi.n.y, poi.n.z, 0.0f);
+    pp->matId = poi.matId;
+}
+
+// code.cl:1073-1193, 1195-1321
+template <int KIND>
+__global__ void __launch_bounds__(256) k_anyhit(uint32_t total, RayAoS* shadow, const float4* prims, const uint32_t* off,
+                                                 Box8 bound8, uint32_t n, uint32_t gsz) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= gsz || id >= total) return;
+    Ray sh = load_ray(&shadow[id]);
+    if (sh.mint == sh.maxt) return;
+    Grid g;
+    g.prims = prims; g.off = off; g.bound = mk_box(bound8); g.n = n;
+    any_hit<KIND>(sh, g);
+    *reinterpret_cast<float2*>(reinterpret_cast<float4*>(&shadow[id]) + 2) = make_float2(sh.mint, sh.maxt);
+}
+
+// code.cl:1323-1364.  `nmat` guards the material fetch: an out-of-range id (undefined
+// behaviour in the reference) shades nothing here instead of reading foreign memory.
+__global__ void __launch_bounds__(256) k_sceneRender(float4* acu, PoiAoS* pois, const RayAoS* shadow, const float4* material,
+                                                      uint32_t nmat, F16 light, uint32_t total, uint32_t gsz) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= gsz || id >= total) return;
+    PoiAoS* pp = &pois[id];
+    int32_t m = pp->matId;
+    if (m < 0 || (uint32_t)m >= nmat) return;
+    Poi poi;
+    poi.p = mk3(pp->px, pp->py, pp->pz);
+    poi.n = mk3(pp->nx, pp->ny, pp->nz);
+    poi.atte = mk3(pp->ax, pp->ay, pp->az);
+    Ray sh = load_ray(&shadow[id]);
+    float4 c4 = material[m];
+    f3 c = shade_vertex(poi, sh, mk3(c4.x, c4.y, c4.z), ld3(light.v), ld3(light.v + 3), ld3(light.v + 6), light.v[9]);
+    pp->ax = poi.atte.x; pp->ay = poi.atte.y; pp->az = poi.atte.z;
+    float4 a = acu[id];
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0f;
+    acu[id] = a;
+}
+
+// code.cl:1366-1386; `radiance` (optional) receives the un-scaled sequential fp32 sums.
+__global__ void __launch_bounds__(256) k_copyToPixel(uchar4* pixel, const float4* acu, float m, uint32_t pixels, uint32_t rpp,
+                                                      uint32_t gsz, float4* radiance) {
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= gsz || id >= pixels) return;
+    const float4* a = acu + (size_t)id * rpp;
+    float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t i = 0; i < rpp; ++i) {
+        float4 v = a[i];
+        c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;
+    }
+    if (radiance) radiance[id] = c;
+    float s = 255.0f * m;
+    c.x = cl_clamp((c.x * s) * 1.8f, 0.0f, 255.0f);
+    c.y = cl_clamp((c.y * s) * 1.8f, 0.0f, 255.0f);
+    c.z = cl_clamp((c.z * s) * 1.8f, 0.0f, 255.0f);
+    if (pixel) pixel[id] = make_uchar4((unsigned char)f2u(c.x), (unsigned char)f2u(c.y), (unsigned char)f2u(c.z), 255);
+}
+
+// splitmix32-style seed fill: s[id] = 1 + (mix(id ^ 0x9E3779B9 ^ base) mod 2147483646), ids global
+// (SURVEY 8d config 4); the reference seeds with Math.random() on the host (A10 code.js:1140-1146).
+__global__ void __launch_bounds__(256) k_seedFill(int32_t* seeds, uint64_t first, uint64_t count, uint32_t base) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t x = (uint32_t)(first + i) ^ 0x9E3779B9u ^ base;
+    uint32_t z = x + 0x9E3779B9u;
+    z = (z ^ (z >> 16)) * 0x85EBCA6Bu;
+    z = (z ^ (z >> 13)) * 0xC2B2AE35u;
+    z = z ^ (z >> 16);
+    seeds[i] = (int32_t)(1u + (z % 2147483646u));
+}
+
+// Diagnostic: evaluates one primitive of the numerics contract element-wise, so tests can
+// compare the device's bits with the CPU's over millions of inputs (tests/test_gpu_numerics.py).
+__global__ void __launch_bounds__(256) k_numerics(int op, const float* a, const float* b, float* out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f, t;
+    switch (op) {
+        case 0: r = x / y; break;
+        case 1: r = cl_sqrt(x); break;
+        case 2: cl_sincos(x, r, t); break;
+        case 3: cl_sincos(x, t, r); break;
+        case 4: { int32_t s = __float_as_int(x); r = get_rand(s); break; }          // LCG step + float map
+        case 5: { int32_t s = __float_as_int(x); r = __int_as_float(lcg_next(s)); break; }  // raw next state
+        case 6: r = cl_min(x, y); break;
+        case 7: r = cl_max(x, y); break;
+        case 8: r = cl_fmin(x, y); break;
+        case 9: r = cl_fmax(x, y); break;
+        case 10: { f3 v = norm3(mk3(x, y, 1.0f)); r = v.x; break; }
+        case 11: concentric(x, y, r, t); break;
+        case 12: concentric(x, y, t, r); break;
+        case 13: r = __int_as_float(f2i(x)); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+}  // namespace pt
+
+// ---- launchers (C++ linkage, called by the C-ABI layer) -----------------------------------
+namespace pt {
+
+static inline dim3 grid1(uint64_t n, unsigned b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+void launch_sizeof(hipStream_t s, bool ray, uint32_t* out) {
+    if (ray) hipLaunchKernelGGL(k_sizeofRay, dim3(1), dim3(64), 0, s, out);
+    else hipLaunchKernelGGL(k_sizeofPoi, dim3(1), dim3(64), 0, s, out);
+}
+void launch_initAcu(hipStream_t s, void* acu, uint32_t total, uint32_t gsz) {
+    if (!gsz) return;
+    hipLaunchKernelGGL(k_initAcu, grid1(gsz), dim3(256), 0, s, (float4*)acu, total, gsz);
+}
+void launch_lensDraws(hipStream_t s, void* seeds, void* uv, uint32_t cols, uint32_t rows, uint32_t gx, uint32_t gy,
+                      uint32_t row0, uint32_t nrows) {
+    if (!cols) return;
+    hipLaunchKernelGGL(k_lensDraws, grid1(cols, 64), dim3(64), 0, s, (int32_t*)seeds, (float2*)uv, cols, rows, gx, gy, row0, nrows);
+}
+void launch_initTrace(hipStream_t s, void* rays, void* pois, const void* uv, const float* bound, const float* cam,
+                      float focal, float lens_rad, uint32_t rpp, uint32_t gx, uint32_t gy) {
+    if (!gx || !gy) return;
+    Box8 b; F16 c;
+    for (int i = 0; i < 8; ++i) b.v[i] = bound[i];
+    for (int i = 0; i < 16; ++i) c.v[i] = cam[i];
+    dim3 blk(32, 8);
+    dim3 grd((gx + 31) / 32, (gy + 7) / 8);
+    hipLaunchKernelGGL(k_initTrace, grd, blk, 0, s, (RayAoS*)rays, (PoiAoS*)pois, (const float2*)uv, b, c, focal, lens_rad, rpp, gx, gy);
+}
+void launch_bouncePaths(hipStream_t s, const void* pois, void* rays, void* seeds, uint32_t total, uint32_t gsz) {
+    if (!gsz) return;
+    hipLaunchKernelGGL(k_bouncePaths, grid1(gsz), dim3(256), 0, s, (const PoiAoS*)pois, (RayAoS*)rays, (int32_t*)seeds, total, gsz);
+}
+static F16 mk16(const float* f) { F16 r; for (int i = 0; i < 16; ++i) r.v[i] = f[i]; return r; }
+static Box8 mk8(const float* f) { Box8 r; for (int i = 0; i < 8; ++i) r.v[i] = f[i]; return r; }
+
+void launch_lightRender(hipStream_t s, void* pois, void* rays, void* acu, const float* light, uint32_t total, uint32_t gsz) {
+    if (!gsz) return;
+    hipLaunchKernelGGL(k_lightRender, grid1(gsz), dim3(256), 0, s, (PoiAoS*)pois, (RayAoS*)rays, (float4*)acu, mk16(light), total, gsz);
+}
+void launch_initShadowTrace(hipStream_t s, void* shadow, const void* pois, uint32_t total, const float* light, void* seeds, uint32_t gsz) {
+    if (!gsz) return;
+    hipLaunchKernelGGL(k_initShadowTrace, grid1(gsz), dim3(256), 0, s, (RayAoS*)shadow, (const PoiAoS*)pois, total, mk16(light), (int32_t*)seeds, gsz);
+}
+void launch_closest(hipStream_t s, int kind, uint32_t total, void* pois, void* rays, const void* prims, const void* normals,
+                    const void* matid, uint32_t mesh_matid, const void* off, const float* bound, uint32_t n, uint32_t gsz) {
+    if (!gsz) return;
+    if (kind == SPHERES)
+        hipLaunchKernelGGL(k_closest<SPHERES>, grid1(gsz), dim3(256), 0, s, total, (PoiAoS*)pois, (RayAoS*)rays, (const float4*)prims,
+                           (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, gsz);
+    else
+        hipLaunchKernelGGL(k_closest<TRIANGLES>, grid1(gsz), dim3(256), 0, s, total, (PoiAoS*)pois, (RayAoS*)rays, (const float4*)prims,
+                           (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, gsz);
+}
+void launch_anyhit(hipStream_t s, int kind, uint32_t total, void* shadow, const void* prims, const void* off, const float* bound,
+                   uint32_t n, uint32_t gsz) {
+    if (!gsz) return;
+    if (kind == SPHERES)
+        hipLaunchKernelGGL(k_anyhit<SPHERES>, grid1(gsz), dim3(256), 0, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, gsz);
+    else
+        hipLaunchKernelGGL(k_anyhit<TRIANGLES>, grid1(gsz), dim3(256), 0, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, gsz);
+}
+void launch_sceneRender(hipStream_t s, void* acu, void* pois, const void* shadow, const void* material, uint32_t nmat,
+                        const float* light, uint32_t total, uint32_t gsz) {
+    if (!gsz) return;
+    hipLaunchKernelGGL(k_sceneRender, grid1(gsz), dim3(256), 0, s, (float4*)acu, (PoiAoS*)pois, (const RayAoS*)shadow, (const float4*)material,
+                       nmat, mk16(light), total, gsz);
+}
+void launch_copyToPixel(hipStream_t s, void* pixel, const void* acu, float m, uint32_t pixels, uint32_t rpp, uint32_t gsz, void* radiance) {
+    if (!gsz) return;
+    hipLaunchKernelGGL(k_copyToPixel, grid1(gsz), dim3(256), 0, s, (uchar4*)pixel, (const float4*)acu, m, pixels, rpp, gsz, (float4*)radiance);
+}
+void launch_numerics(hipStream_t s, int op, const void* a, const void* b, void* out, uint64_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_numerics, grid1(n), dim3(256), 0, s, op, (const float*)a, (const float*)b, (float*)out, n);
+}
+void launch_seedFill(hipStream_t s, void* seeds, uint64_t first, uint64_t count, uint32_t base) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_seedFill, grid1(count), dim3(256), 0, s, (int32_t*)seeds, first, count, base);
+}
+
+}  // namespace pt

@@ -1,0 +1,68 @@
+// pt_launch.hpp -- host-callable launchers of the kernel families (C++ linkage; the C ABI
+// in mirt_abi.cpp is the only caller).  All launches are asynchronous on `s`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pt {
+
+enum { KIND_SPHERES = 0, KIND_TRIANGLES = 1 };
+
+// ---- reference-shaped kernels (pt_kernels_granular.hip) ------------------------------------
+void launch_sizeof(hipStream_t s, bool ray, uint32_t* out);
+void launch_initAcu(hipStream_t s, void* acu, uint32_t total, uint32_t gsz);
+void launch_lensDraws(hipStream_t s, void* seeds, void* uv, uint32_t cols, uint32_t rows, uint32_t gx, uint32_t gy,
+                      uint32_t row0, uint32_t nrows);
+void launch_initTrace(hipStream_t s, void* rays, void* pois, const void* uv, const float* bound, const float* cam,
+                      float focal, float lens_rad, uint32_t rpp, uint32_t gx, uint32_t gy);
+void launch_bouncePaths(hipStream_t s, const void* pois, void* rays, void* seeds, uint32_t total, uint32_t gsz);
+void launch_lightRender(hipStream_t s, void* pois, void* rays, void* acu, const float* light, uint32_t total, uint32_t gsz);
+void launch_initShadowTrace(hipStream_t s, void* shadow, const void* pois, uint32_t total, const float* light, void* seeds, uint32_t gsz);
+void launch_closest(hipStream_t s, int kind, uint32_t total, void* pois, void* rays, const void* prims, const void* normals,
+                    const void* matid, uint32_t mesh_matid, const void* off, const float* bound, uint32_t n, uint32_t gsz);
+void launch_anyhit(hipStream_t s, int kind, uint32_t total, void* shadow, const void* prims, const void* off, const float* bound,
+                   uint32_t n, uint32_t gsz);
+void launch_sceneRender(hipStream_t s, void* acu, void* pois, const void* shadow, const void* material, uint32_t nmat,
+                        const float* light, uint32_t total, uint32_t gsz);
+void launch_copyToPixel(hipStream_t s, void* pixel, const void* acu, float m, uint32_t pixels, uint32_t rpp, uint32_t gsz, void* radiance);
+void launch_numerics(hipStream_t s, int op, const void* a, const void* b, void* out, uint64_t n);
+void launch_seedFill(hipStream_t s, void* seeds, uint64_t first, uint64_t count, uint32_t base);
+
+// ---- fused pass (pt_kernels_fused.hip) -------------------------------------------------------
+constexpr int kMaxLights = 8;
+constexpr int kMaxMeshes = 16;
+
+struct GridArgs {            // one cell-sorted primitive set, device pointers
+    const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per triangle
+    const void* normals;     // 3 x float4 per triangle (null for spheres)
+    const void* matid;       // uint per primitive (null: use `mesh_matid`)
+    const void* off;         // uint[n^3 + 1]
+    float bound[8];          // (min,1,max,1)
+    uint32_t n;              // cells per axis
+    uint32_t mesh_matid;
+};
+struct LightArgs {           // the three float16 packings of one light (A10 code.js:323-352)
+    float shadow[16];        // pos, T, B, radius
+    float scene[16];         // pos, normal, irradiance, area
+    float light[16];         // pos, normal, irradiance, radius
+};
+struct FusedArgs {
+    float cam[16];
+    float bound[8];
+    float focal_length, lens_rad;
+    uint32_t width, height, rpp;
+    uint32_t row0, nrows;    // row tile this launch renders; per-ray buffers are tile-local
+    uint32_t bounces;        // 5 in the reference (A10 code.js:1829)
+    uint32_t has_spheres, has_triangles, n_meshes, n_lights;
+    GridArgs spheres, triangles;
+    GridArgs meshes[kMaxMeshes];
+    LightArgs lights[kMaxLights];
+    const void* material;    // float4[nmat]
+    uint32_t nmat;
+    int32_t* seeds;          // [nrows*width*rpp], read-modify-write
+    void* acu;               // float4[nrows*width*rpp], accumulated into
+    const void* uv;          // rpp == 1: float2[nrows*width] lens draws from launch_lensDraws
+};
+void launch_fused(hipStream_t s, const FusedArgs& a);
+
+}  // namespace pt

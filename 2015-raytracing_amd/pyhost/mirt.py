@@ -1,0 +1,328 @@
+"""ctypes binding of include/mirt.h -- tooling for tests/, bench.py and smoke().
+
+The product host is JavaScript (2015-raytracing_amd/host/, over the N-API addon); this
+module exists because the driver's bench/test contract is Python.  It adds nothing to
+the C ABI: every method is one mirt_* call, errors become MirtError carrying
+mirt_last_error().  There is NO CPU fallback here or below: without libmirt.so or without
+a gfx950 device every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmirt.so")
+
+MEM_READ_WRITE, MEM_WRITE_ONLY, MEM_READ_ONLY = 1, 2, 4
+MAX_LIGHTS, MAX_MESHES = 8, 16
+
+
+class MirtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mirt error {code}: {msg}")
+        self.code = code
+
+
+class _Grid(C.Structure):
+    _fields_ = [("prims", C.c_void_p), ("normals", C.c_void_p), ("matid", C.c_void_p), ("cell_offsets", C.c_void_p),
+                ("bounds", C.c_float * 8), ("n_slabs", C.c_uint32), ("mesh_matid", C.c_uint32)]
+
+
+class _Light(C.Structure):
+    _fields_ = [("shadow", C.c_float * 16), ("scene", C.c_float * 16), ("light", C.c_float * 16)]
+
+
+class _PassDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("rays_per_pixel", C.c_uint32),
+                ("row0", C.c_uint32), ("nrows", C.c_uint32), ("bounces", C.c_uint32), ("pass_index", C.c_uint32),
+                ("cam", C.c_float * 16), ("scene_bounds", C.c_float * 8), ("focal_length", C.c_float), ("lens_rad", C.c_float),
+                ("n_lights", C.c_uint32), ("n_meshes", C.c_uint32),
+                ("spheres", C.POINTER(_Grid)), ("triangles", C.POINTER(_Grid)), ("meshes", C.POINTER(_Grid)),
+                ("lights", C.POINTER(_Light)),
+                ("material", C.c_void_p), ("seeds", C.c_void_p), ("acu", C.c_void_p), ("pixel", C.c_void_p), ("radiance", C.c_void_p)]
+
+
+_lib = None
+
+# name -> (restype, argtypes): every symbol include/mirt.h declares
+SYMBOLS = {
+    "mirt_device_count": (C.c_int, []),
+    "mirt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "mirt_version": (C.c_char_p, []),
+    "mirt_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mirt_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "mirt_last_error": (C.c_char_p, [C.c_void_p]),
+    "mirt_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mirt_finish": (C.c_int, [C.c_void_p]),
+    "mirt_buf_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint, C.POINTER(C.c_void_p)]),
+    "mirt_buf_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mirt_buf_release": (C.c_int, [C.c_void_p]),
+    "mirt_buf_size": (C.c_size_t, [C.c_void_p]),
+    "mirt_buf_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "mirt_buf_write": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
+    "mirt_buf_read": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
+    "mirt_program_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "mirt_kernel_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "mirt_kernel_release": (C.c_int, [C.c_void_p]),
+    "mirt_kernel_num_args": (C.c_int, [C.c_void_p]),
+    "mirt_kernel_set_arg": (C.c_int, [C.c_void_p, C.c_uint, C.c_size_t, C.c_void_p]),
+    "mirt_kernel_set_arg_buf": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p]),
+    "mirt_kernel_preferred_multiple": (C.c_int, [C.c_void_p]),
+    "mirt_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "mirt_render_pass": (C.c_int, [C.c_void_p, C.POINTER(_PassDesc)]),
+    "mirt_seed_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "mirt_zero": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mirt_timer_start": (C.c_int, [C.c_void_p]),
+    "mirt_timer_stop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "mirt_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "mirt_pass_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mirt_debug_numerics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+}
+
+
+def lib():
+    """Load libmirt.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MirtError(-7, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def device_count():
+    return lib().mirt_device_count()
+
+
+class Buffer:
+    def __init__(self, ctx, handle, nbytes):
+        self.ctx, self.h, self.nbytes = ctx, handle, nbytes
+
+    def write(self, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        self.ctx._chk(lib().mirt_buf_write(self.h, offset, a.nbytes, a.ctypes.data_as(C.c_void_p), 0))
+        return self
+
+    def read(self, dtype, count=None, offset=0):
+        dt = np.dtype(dtype)
+        n = (self.nbytes - offset) // dt.itemsize if count is None else count
+        out = np.empty(n, dt)
+        self.ctx._chk(lib().mirt_buf_read(self.h, offset, out.nbytes, out.ctypes.data_as(C.c_void_p), 1))
+        return out
+
+    @property
+    def device_ptr(self):
+        return lib().mirt_buf_device_ptr(self.h)
+
+    def release(self):
+        if self.h:
+            self.ctx._chk(lib().mirt_buf_release(self.h))
+            self.h = None
+
+
+class Kernel:
+    """program.createKernel(name): setArg takes a Buffer or a numpy array, as WebCL takes a typed array."""
+
+    def __init__(self, ctx, name):
+        self.ctx, self.name = ctx, name
+        h = C.c_void_p()
+        ctx._chk(lib().mirt_kernel_get(ctx.h, name.encode(), C.byref(h)))
+        self.h = h
+
+    def set_arg(self, i, v):
+        if isinstance(v, Buffer):
+            self.ctx._chk(lib().mirt_kernel_set_arg_buf(self.h, i, v.h))
+        else:
+            a = np.ascontiguousarray(v)
+            self.ctx._chk(lib().mirt_kernel_set_arg(self.h, i, a.nbytes, a.ctypes.data_as(C.c_void_p)))
+        return self
+
+    def set_args(self, *vals):
+        for i, v in enumerate(vals):
+            if v is not None:
+                self.set_arg(i, v)
+        return self
+
+    def enqueue(self, global_ws, local_ws=None):
+        g = (C.c_size_t * len(global_ws))(*global_ws)
+        l = (C.c_size_t * len(local_ws))(*local_ws) if local_ws else None
+        self.ctx._chk(lib().mirt_enqueue(self.ctx.h, self.h, len(global_ws), g, l))
+
+    def release(self):
+        if self.h:
+            self.ctx._chk(lib().mirt_kernel_release(self.h))
+            self.h = None
+
+
+class Context:
+    """webcl.createContext(device) + ctx.createCommandQueue()."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = lib().mirt_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise MirtError(rc, lib().mirt_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MirtError(rc, lib().mirt_last_error(self.h).decode())
+
+    def last_error(self):
+        return lib().mirt_last_error(self.h).decode()
+
+    def buffer(self, nbytes, flags=MEM_READ_WRITE):
+        h = C.c_void_p()
+        self._chk(lib().mirt_buf_create(self.h, nbytes, flags, C.byref(h)))
+        return Buffer(self, h, nbytes)
+
+    def buffer_from(self, arr, flags=MEM_READ_ONLY):
+        a = np.ascontiguousarray(arr)
+        return self.buffer(max(a.nbytes, 1), flags).write(a) if a.nbytes else self.buffer(16, flags)
+
+    def wrap(self, device_ptr, nbytes):
+        h = C.c_void_p()
+        self._chk(lib().mirt_buf_wrap(self.h, C.c_void_p(device_ptr), nbytes, C.byref(h)))
+        return Buffer(self, h, nbytes)
+
+    def kernel(self, name):
+        return Kernel(self, name)
+
+    def set_stream(self, hip_stream):
+        self._chk(lib().mirt_ctx_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def finish(self):
+        self._chk(lib().mirt_finish(self.h))
+
+    def seed_fill(self, buf, first_ray, count, seed_base=0):
+        self._chk(lib().mirt_seed_fill(self.h, buf.h, first_ray, count, seed_base))
+
+    def zero(self, buf):
+        self._chk(lib().mirt_zero(self.h, buf.h))
+
+    def timer_start(self):
+        self._chk(lib().mirt_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._chk(lib().mirt_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on=True):
+        self._chk(lib().mirt_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def pass_timing(self):
+        a, b = C.c_float(), C.c_float()
+        self._chk(lib().mirt_pass_timing(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def program_check(self, source):
+        miss = C.create_string_buffer(1024)
+        n = lib().mirt_program_check(self.h, source.encode(), miss, 1024)
+        if n < 0:
+            self._chk(n)
+        return n, miss.value.decode()
+
+    def debug_numerics(self, op, a, b=None):
+        a = np.ascontiguousarray(a, np.float32)
+        n = a.size
+        da = self.buffer_from(a, MEM_READ_WRITE)
+        db = self.buffer_from(np.ascontiguousarray(b, np.float32), MEM_READ_WRITE) if b is not None else None
+        do = self.buffer(max(4 * n, 16))
+        self._chk(lib().mirt_debug_numerics(self.h, op, da.h, db.h if db else None, do.h, n))
+        out = do.read(np.float32, n)
+        for x in (da, db, do):
+            if x:
+                x.release()
+        return out
+
+    def render_pass(self, desc):
+        self._chk(lib().mirt_render_pass(self.h, C.byref(desc)))
+
+    def destroy(self):
+        if self.h:
+            lib().mirt_ctx_destroy(self.h)
+            self.h = None
+
+
+def _f(arr, n):
+    return (C.c_float * n)(*[float(x) for x in np.asarray(arr, np.float32).ravel()[:n]])
+
+
+class DeviceScene:
+    """Uploads the packed kernel inputs of one scene (the arrays the reference host would
+    enqueueWriteBuffer: A10 code.js:1183-1185, 1231-1234, 1276-1278, 1379) and keeps the
+    handles.  `s` is a pyhost.scene.PackedScene (or anything with its attributes)."""
+
+    def __init__(self, ctx, s):
+        self.ctx, self.s = ctx, s
+        self.bufs = []
+        up = self._up
+        self.sph = self.tri = None
+        if s.has_spheres:
+            self.sph = dict(prims=up(s.spheres), matid=up(s.s_matid), off=up(s.s_box), bounds=s.sphere_bounds, n=s.n_slabs)
+        if s.has_triangles:
+            self.tri = dict(prims=up(s.t_pos), normals=up(s.t_normal), matid=up(s.t_matid), off=up(s.t_box),
+                            bounds=s.triangle_bounds, n=s.n_slabs)
+        self.meshes = [dict(prims=up(m["pos"]), normals=up(m["normal"]), off=up(m["box"]), bounds=m["bounds"],
+                            n=m["nslabs"], matid=m["matid"]) for m in s.meshes]
+        self.material = up(s.materials)
+
+    def _up(self, arr):
+        b = self.ctx.buffer_from(arr)
+        self.bufs.append(b)
+        return b
+
+    def _grid(self, g, mesh=False):
+        out = _Grid()
+        out.prims = g["prims"].h
+        out.normals = g["normals"].h if "normals" in g else None
+        out.matid = None if mesh else g["matid"].h
+        out.cell_offsets = g["off"].h
+        out.bounds = _f(g["bounds"], 8)
+        out.n_slabs = int(g["n"])
+        out.mesh_matid = int(g["matid"]) if mesh else 0
+        return out
+
+    def pass_desc(self, seeds, acu, pixel=None, radiance=None, pass_index=1, bounces=5, row0=0, nrows=0):
+        s = self.s
+        d = _PassDesc()
+        d.struct_size = C.sizeof(_PassDesc)
+        d.width, d.height, d.rays_per_pixel = s.width, s.height, s.rpp
+        d.row0, d.nrows, d.bounces, d.pass_index = row0, nrows, bounces, pass_index
+        d.cam = _f(s.cam, 16)
+        d.scene_bounds = _f(s.bounds, 8)
+        d.focal_length, d.lens_rad = s.focal_length, s.lens_rad
+        keep = []
+        if self.sph:
+            g = self._grid(self.sph); keep.append(g); d.spheres = C.pointer(g)
+        if self.tri:
+            g = self._grid(self.tri); keep.append(g); d.triangles = C.pointer(g)
+        if self.meshes:
+            arr = (_Grid * len(self.meshes))(*[self._grid(m, mesh=True) for m in self.meshes])
+            keep.append(arr); d.meshes = C.cast(arr, C.POINTER(_Grid))
+        d.n_meshes = len(self.meshes)
+        larr = (_Light * max(1, len(s.lights)))()
+        for i, l in enumerate(s.lights):
+            larr[i].shadow, larr[i].scene, larr[i].light = _f(l["shadow"], 16), _f(l["scene"], 16), _f(l["light"], 16)
+        keep.append(larr)
+        d.lights = C.cast(larr, C.POINTER(_Light))
+        d.n_lights = len(s.lights)
+        d.material = self.material.h
+        d.seeds, d.acu = seeds.h, acu.h
+        d.pixel = pixel.h if pixel else None
+        d.radiance = radiance.h if radiance else None
+        d._keep = keep
+        return d
+
+    def release(self):
+        for b in self.bufs:
+            b.release()
+        self.bufs = []

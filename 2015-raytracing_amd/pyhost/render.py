@@ -1,0 +1,206 @@
+"""Pass drivers over the C ABI, in Python, for tests and bench.py.
+
+`GranularRenderer` is a line-by-line functional mirror of the reference host's kernel
+plumbing -- preRender() / executeRender() of A10 code.js:1784-1854 with its prepare*/execute*
+helpers (:1078-1528) -- written against pyhost.mirt instead of WebCL: same kernels, same
+argument indices, same enqueue order, same NDRange padding.  It exists so that the parity
+tests read like the reference's own call sequence.  `FusedRenderer` is the one-launch path
+(mirt_render_pass).  The JavaScript host in ../host/ has the same two drivers; that is the
+product, this is tooling.
+"""
+import math
+
+import numpy as np
+
+from . import mirt
+
+RAY_BYTES, POI_BYTES = 48, 64
+
+
+def _u32(v):
+    return np.array([v], np.uint32)
+
+
+def _f32(v):
+    return np.array([v], np.float32)
+
+
+def get_local_ws(dim, multiple):
+    """getLocalWS (A10 code.js:645-672)."""
+    if dim == 1:
+        return [multiple]
+    x = int(math.floor(math.sqrt(multiple)))
+    if x & (x - 1):
+        x = 1 << (x - 1).bit_length()
+    return [x, multiple // x]
+
+
+class GranularRenderer:
+    def __init__(self, ctx, scene, seeds=None, seed_base=0):
+        self.ctx, self.s = ctx, scene
+        self.dev = mirt.DeviceScene(ctx, scene)
+        self.k, self.b, self.gws, self.lws = {}, {}, {}, {}
+        self.passes = 1
+        self._pre_render(seeds, seed_base)
+
+    # -- preRender (code.js:1784-1804)
+    def _pre_render(self, seeds, seed_base):
+        ctx, s = self.ctx, self.s
+        n = s.total_rays
+        self.total_rays = n
+        # getStructSize (code.js:1064-1076)
+        sizes = {}
+        for name in ("Ray", "Poi"):
+            k = ctx.kernel("sizeof" + name)
+            tmp = ctx.buffer(4, mirt.MEM_WRITE_ONLY)
+            k.set_arg(0, tmp)
+            k.enqueue([1], [1])
+            sizes[name] = int(tmp.read(np.uint32, 1)[0])
+            tmp.release()
+            k.release()
+        self.ray_size, self.poi_size = sizes["Ray"], sizes["Poi"]
+
+        # prepareInitAcu (code.js:1078-1099)
+        self.b["acu"] = ctx.buffer(n * 16)
+        k = ctx.kernel("initAcu").set_args(self.b["acu"], _u32(n))
+        l = get_local_ws(1, 64)
+        k.enqueue([-(-n // l[0]) * l[0]], l)
+        ctx.finish()
+        k.release()
+        # prepareInitSeeds (code.js:1140-1154)
+        self.b["seeds"] = ctx.buffer(n * 4)
+        if seeds is not None:
+            self.b["seeds"].write(np.asarray(seeds, np.int32))
+        else:
+            ctx.seed_fill(self.b["seeds"], 0, n, seed_base)
+        # prepareInitTrace (code.js:1101-1138)
+        self.b["rays"] = ctx.buffer(n * self.ray_size)
+        self.b["pois"] = ctx.buffer(n * self.poi_size)
+        self.k["initTrace"] = ctx.kernel("initTrace").set_args(
+            self.b["seeds"], self.b["rays"], self.b["pois"], s.bounds, None, _f32(s.focal_length), _f32(s.lens_rad), _u32(s.rpp))
+        l = get_local_ws(2, 64)
+        self.lws["initTrace"] = l
+        self.gws["initTrace"] = [-(-s.width // l[0]) * l[0], -(-s.height // l[1]) * l[1]]
+        g1 = [-(-n // 64) * 64]
+        d = self.dev
+        if s.has_spheres:  # prepareSphereTrace (code.js:1156-1202)
+            self.k["sphereTrace"] = ctx.kernel("sphereTrace").set_args(
+                _u32(n), self.b["pois"], self.b["rays"], d.sph["prims"], d.sph["matid"], d.sph["off"], s.sphere_bounds, _u32(s.n_slabs))
+        if s.has_triangles:  # prepareTriangleTrace (code.js:1204-1252)
+            self.k["triangleTrace"] = ctx.kernel("triangleTrace").set_args(
+                _u32(n), self.b["pois"], self.b["rays"], d.tri["prims"], d.tri["normals"], d.tri["matid"], d.tri["off"],
+                s.triangle_bounds, _u32(s.n_slabs))
+        if s.meshes:  # prepareMeshTrace (code.js:1254-1291)
+            self.k["meshTrace"] = ctx.kernel("meshTrace").set_args(_u32(n), self.b["pois"], self.b["rays"])
+        # prepareInitShadowTrace (code.js:1417-1442)
+        self.b["shadow"] = ctx.buffer(n * self.ray_size)
+        self.k["initShadowTrace"] = ctx.kernel("initShadowTrace").set_args(self.b["shadow"], self.b["pois"], _u32(n), None, self.b["seeds"])
+        if s.has_spheres:  # prepareSphereShadowTrace (code.js:1461-1479)
+            self.k["sphereShadowTrace"] = ctx.kernel("sphereShadowTrace").set_args(
+                _u32(n), self.b["shadow"], d.sph["prims"], d.sph["off"], s.sphere_bounds, _u32(s.n_slabs))
+        if s.has_triangles or s.meshes:  # prepareTriangleShadowTrace (code.js:1481-1499)
+            self.k["triangleShadowTrace"] = ctx.kernel("triangleShadowTrace").set_args(_u32(n), self.b["shadow"])
+        # prepareSceneRender (code.js:1364-1395)
+        self.k["sceneRender"] = ctx.kernel("sceneRender").set_args(self.b["acu"], self.b["pois"], self.b["shadow"], d.material, None, _u32(n))
+        # prepareCopyToPixel (code.js:1305-1326)
+        npix = s.width * s.height
+        self.b["pixel"] = ctx.buffer(npix * 4, mirt.MEM_WRITE_ONLY)
+        self.k["copyToPixel"] = ctx.kernel("copyToPixel").set_args(self.b["pixel"], self.b["acu"], None, _u32(npix), _u32(s.rpp))
+        self.gws["copyToPixel"] = [-(-npix // 64) * 64]
+        # prepareBouncePaths (code.js:1444-1459), prepareLightRender (code.js:1346-1362)
+        self.k["bouncePaths"] = ctx.kernel("bouncePaths").set_args(self.b["pois"], self.b["rays"], self.b["seeds"], _u32(n))
+        self.k["lightRender"] = ctx.kernel("lightRender").set_args(self.b["pois"], self.b["rays"], self.b["acu"], None, _u32(n))
+        self.g1 = g1
+
+    def _closest(self):
+        s, k, d = self.s, self.k, self.dev
+        if s.has_spheres:
+            k["sphereTrace"].enqueue(self.g1, [64])
+        if s.has_triangles:
+            k["triangleTrace"].enqueue(self.g1, [64])
+        for m in d.meshes:  # executeMeshTrace (code.js:1293-1303)
+            k["meshTrace"].set_arg(3, m["prims"]).set_arg(4, m["normals"]).set_arg(5, m["off"]).set_arg(6, _u32(m["matid"]))
+            k["meshTrace"].set_arg(7, m["bounds"]).set_arg(8, _u32(m["n"]))
+            k["meshTrace"].enqueue(self.g1, [64])
+
+    def _direct(self):
+        s, k, d = self.s, self.k, self.dev
+        for l in s.lights:
+            k["initShadowTrace"].set_arg(3, l["shadow"]).enqueue(self.g1, [64])
+            if s.has_spheres:
+                k["sphereShadowTrace"].enqueue(self.g1, [64])
+            if s.has_triangles:  # executeTriangleShadowTrace (code.js:1514-1520)
+                k["triangleShadowTrace"].set_arg(2, d.tri["prims"]).set_arg(3, d.tri["off"]).set_arg(4, s.triangle_bounds).set_arg(5, _u32(s.n_slabs))
+                k["triangleShadowTrace"].enqueue(self.g1, [64])
+            for m in d.meshes:  # executeMeshShadowTrace (code.js:1522-1528)
+                k["triangleShadowTrace"].set_arg(2, m["prims"]).set_arg(3, m["off"]).set_arg(4, m["bounds"]).set_arg(5, _u32(m["n"]))
+                k["triangleShadowTrace"].enqueue(self.g1, [64])
+            k["sceneRender"].set_arg(4, l["scene"]).enqueue(self.g1, [64])  # executeSceneRender (code.js:1402-1408)
+            self.ctx.finish()
+
+    # -- executeRender (code.js:1806-1854)
+    def execute_render(self, bounces=5, on_primary=None):
+        s, k = self.s, self.k
+        k["initTrace"].set_arg(4, s.cam).enqueue(self.gws["initTrace"], self.lws["initTrace"])
+        self._closest()
+        for l in s.lights:
+            k["lightRender"].set_arg(3, l["light"]).enqueue(self.g1, [64])
+        self._direct()
+        if on_primary:
+            on_primary(self)
+        for _ in range(bounces):
+            k["bouncePaths"].enqueue(self.g1, [64])
+            self._closest()
+            self._direct()
+        div = np.float32(1.0 / (s.rpp * self.passes))  # executeCopyToPixel (code.js:1410-1415)
+        k["copyToPixel"].set_arg(2, _f32(div)).enqueue(self.gws["copyToPixel"], [64])
+        self.ctx.finish()
+        self.passes += 1
+
+    def read(self, name):
+        from_dt = {"seeds": np.int32, "acu": np.float32, "pixel": np.uint8, "rays": np.uint8, "pois": np.uint8, "shadow": np.uint8}
+        return self.b[name].read(from_dt[name])
+
+    def release(self):
+        for k in self.k.values():
+            k.release()
+        for b in self.b.values():
+            b.release()
+        self.dev.release()
+        self.k, self.b = {}, {}
+
+
+class FusedRenderer:
+    """One mirt_render_pass per progressive pass over rows [row0, row0+nrows)."""
+
+    def __init__(self, ctx, scene, seeds=None, seed_base=0, row0=0, nrows=0, want_radiance=True):
+        self.ctx, self.s = ctx, scene
+        self.dev = mirt.DeviceScene(ctx, scene)
+        self.row0 = row0
+        self.nrows = nrows or scene.height
+        self.npix = self.nrows * scene.width
+        self.nrays = self.npix * scene.rpp
+        self.first_ray = row0 * scene.width * scene.rpp
+        self.seeds = ctx.buffer(self.nrays * 4)
+        if seeds is not None:
+            self.seeds.write(np.asarray(seeds, np.int32)[self.first_ray:self.first_ray + self.nrays])
+        else:
+            ctx.seed_fill(self.seeds, self.first_ray, self.nrays, seed_base)
+        self.acu = ctx.buffer(self.nrays * 16)
+        ctx.zero(self.acu)
+        self.pixel = ctx.buffer(self.npix * 4)
+        self.radiance = ctx.buffer(self.npix * 16) if want_radiance else None
+        self.passes = 1
+        self._desc = None
+
+    def execute_render(self, bounces=5):
+        d = self.dev.pass_desc(self.seeds, self.acu, self.pixel, self.radiance, pass_index=self.passes, bounces=bounces,
+                               row0=self.row0, nrows=self.nrows)
+        self.ctx.render_pass(d)
+        self.passes += 1
+
+    def release(self):
+        for b in (self.seeds, self.acu, self.pixel, self.radiance):
+            if b:
+                b.release()
+        self.dev.release()

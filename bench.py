@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the Assign10 path-tracing pass on N MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3], the one the metric is quoted on): scenes/cornell.xml packed by the
+reference host for 1920x1080, rays_per_pixel = 256 (16x16 lens grid), one progressive pass, 5 bounces,
+seeds s[id] = 1 + (mix32(id ^ 0x9E3779B9) mod 2147483646) generated on the device.  One "step" is one
+such frame: initTrace .. 5 bounces .. copyToPixel, through mirt_render_pass (one fused launch + resolve).
+Inputs (scene buffers, seeds) are resident in HBM before the timed region.
+
+N > 1: one process per GPU; the frame is cut into N contiguous row tiles (ray ids stay global, so the
+image is identical for every N); each step ends with the one real exchange of the path, an RCCL
+all_gather of the RGBA8 tiles.  Total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (pt::k_fusedPass): the binding
+roof of this path is the fp32 vector ALU, so `bound` is "valu" with the 157.3 TFLOP/s
+vector peak; the HBM view the north star asks for rides along in `roofline_hbm`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+# measured constants (DESIGN.md "Algorithmic work"): oracle/liboracle_count.so on cornell.xml 320x240 rpp 16
+FLOPS_PER_SAMPLE = {5: 6632.7, 8: 9812.3}
+BYTES_PER_SAMPLE_FUSED = 40.0       # seed 4 in + 4 out, accumulator 16 in + 16 out
+BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0
+PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA-counted)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(packed_json, log):
+    """The CPU oracle (our plain-C restatement, OpenMP over all host cores) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import a10_pass as A
+    d = json.loads(packed_json)
+    w, h, rpp = 240, 135, 256
+    cam = list(d["cam"])
+    cam[14], cam[15] = float(w), float(h)   # same 16:9 frustum, 1/8 of the pixels per side
+    d.update(cam=cam, width=w, height=h, rays_per_pixel=rpp)
+    sc = A.Scene(d)
+    k = A.load_oracle()
+    k.lib.oracle_num_threads.restype = int
+    cores = k.lib.oracle_num_threads()
+    st = A.PassState(sc, A.make_seeds(sc.total_rays))
+    t0 = time.perf_counter()
+    A.run_pass(k, sc, st)
+    dt = time.perf_counter() - t0
+    log(f"cpu_baseline: {sc.total_rays} samples in {dt:.2f} s on {cores} threads")
+    return {"value": round(sc.total_rays / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"cornell.xml {w}x{h} rpp{rpp} 1 pass 5 bounces ({sc.total_rays} samples, {dt:.1f} s wall)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--rpp", type=int, default=256)
+    ap.add_argument("--bounces", type=int, default=5)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def log(msg):
+        if rank == 0:
+            print(msg, file=sys.stderr, flush=True)
+
+    graft.load_package()
+    from raytracing_amd.pyhost import mirt, render, scene
+
+    name = f"scene_cornell_{args.width}x{args.height}_r{args.rpp}.json"
+    path = os.path.join(ROOT, "tests", "golden", name)
+    if os.path.exists(path):
+        packed = open(path).read()
+        sc = scene.PackedScene(packed)
+    else:  # other sizes: same scene, camera re-packed for the size
+        packed = open(os.path.join(ROOT, "tests", "golden", "scene_cornell_1920x1080_r256.json")).read()
+        sc = scene.PackedScene(packed).resized(args.width, args.height, args.rpp)
+
+    # contiguous row tiles
+    H = sc.height
+    base, extra = divmod(H, world)
+    rows = [base + (1 if r < extra else 0) for r in range(world)]
+    row0 = sum(rows[:rank])
+    nrows = rows[rank]
+    max_rows = max(rows)
+
+    ctx = mirt.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_profiling(True)
+    fr = render.FusedRenderer(ctx, sc, row0=row0, nrows=nrows, want_radiance=True)
+    # the RGBA8 tile lives in a torch tensor so RCCL can move it
+    tile = torch.zeros(max_rows * sc.width * 4, dtype=torch.uint8, device="cuda")
+    fr.pixel.release()
+    fr.pixel = ctx.wrap(tile.data_ptr(), max_rows * sc.width * 4)
+    frame = torch.empty(world * tile.numel(), dtype=torch.uint8, device="cuda") if world > 1 else None
+    seeds0 = None
+
+    def step():
+        # a step re-renders the same frame: restore the accumulator and the seeds it started from
+        ctx.zero(fr.acu)
+        ctx.seed_fill(fr.seeds, fr.first_ray, fr.nrays, 0)
+        fr.passes = 1
+        fr.execute_render(bounces=args.bounces)
+        if world > 1:
+            dist.all_gather_into_tensor(frame, tile)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kern_ms.append(ctx.pass_timing())   # waits for this step's own events only
+    fence()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+
+    samples_per_step = sc.width * sc.height * sc.rpp
+    value = samples_per_step * args.steps / dt / 1e6
+    fused_ms = float(np.mean([k[0] for k in kern_ms]))
+    resolve_ms = float(np.mean([k[1] for k in kern_ms]))
+    local_samples = fr.nrays
+    flops = FLOPS_PER_SAMPLE.get(args.bounces, FLOPS_PER_SAMPLE[5] * (1 + args.bounces) / 6.0)
+    valu_tf = flops * local_samples / (fused_ms * 1e-3) / 1e12
+    hbm_gbs = BYTES_PER_SAMPLE_FUSED * local_samples / (fused_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "Msamples/sec (pixels x spp) at 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "fps": round(args.steps / dt, 3),
+        "config": {"workload": f"A10 cornell.xml path trace {sc.width}x{sc.height}, {sc.rpp} spp (16x16 lens grid), 1 pass, "
+                               f"{args.bounces} bounces, thin lens; fused mirt_render_pass + copyToPixel"
+                               + (f"; {world} row tiles + RCCL all_gather of RGBA8" if world > 1 else ""),
+                   "width": sc.width, "height": sc.height, "rays_per_pixel": sc.rpp, "bounces": args.bounces,
+                   "parallelism": f"rows/{world}"},
+        "roofline": {"kernel": "pt::k_fusedPass", "bound": "valu", "achieved": round(valu_tf, 2), "peak": PEAK_VALU_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(valu_tf / PEAK_VALU_TFLOPS, 4), "traffic": None,
+                     "flops_per_sample": flops, "launch_ms": round(fused_ms, 3), "resolve_ms": round(resolve_ms, 3)},
+        "roofline_hbm": {"kernel": "pt::k_fusedPass", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": None,
+                         "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(packed, log)
+    fr.release()
+    ctx.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

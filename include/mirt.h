@@ -1,0 +1,184 @@
+/*
+ * mirt.h -- C ABI of libmirt.so: the MI355X-native device runtime behind the host
+ * interface of eaymerich/2015-RayTracing's Assign10 path tracer.
+ *
+ * The reference host (Assign10-Path_Tracing/code.js, "A10 code.js" below) talks to its
+ * device through the WebCL 1.0 object model (webcl -> context -> queue / program ->
+ * kernel / buffer).  Each entry point here is what that binding needs underneath; the
+ * comment on each cites the reference call it replaces.  Signatures are plain C
+ * (opaque handles, pointers, sizes); no C++ exception crosses this boundary.
+ *
+ * Conventions
+ *   - return 0 (MIRT_OK) or a negative mirt_status; text via mirt_last_error().
+ *   - host pointers are borrowed for the duration of the call only: reads/writes of
+ *     pageable memory complete before the call returns, whatever `blocking` says (the
+ *     reference passes blocking=false and keeps its typed arrays alive until finish()).
+ *   - one in-order HIP stream per context (A10 code.js:592 createCommandQueue()).
+ *   - handles are reference-free: release exactly once; using a released handle is
+ *     MIRT_E_HANDLE, not undefined behaviour (handles are validated against a live set).
+ *   - single host thread per context (the reference is a single JS thread).
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MIRT_API __attribute__((visibility("default")))
+#else
+#define MIRT_API
+#endif
+
+typedef struct mirt_ctx mirt_ctx;
+typedef struct mirt_buf mirt_buf;
+typedef struct mirt_kernel mirt_kernel;
+
+typedef enum mirt_status {
+    MIRT_OK = 0,
+    MIRT_E_ARG = -1,        /* bad argument (null, size mismatch, index out of range)        */
+    MIRT_E_HANDLE = -2,     /* unknown or already released handle                            */
+    MIRT_E_NAME = -3,       /* no kernel of that name (WebCL: INVALID_KERNEL_NAME)           */
+    MIRT_E_UNSET = -4,      /* enqueue with an argument never set (INVALID_KERNEL_ARGS)      */
+    MIRT_E_RANGE = -5,      /* buffer too small for what the launch would touch              */
+    MIRT_E_DEVICE = -6,     /* HIP runtime error (message has the hipError string)           */
+    MIRT_E_NODEVICE = -7,   /* no gfx950 device / extension not usable                       */
+    MIRT_E_DATA = -8        /* device data failed validation (cell offsets not monotone ...) */
+} mirt_status;
+
+/* WebCL memory flags (A10 code.js:1083, 1175, 1312: MEM_READ_WRITE / MEM_READ_ONLY / MEM_WRITE_ONLY) */
+#define MIRT_MEM_READ_WRITE 1u
+#define MIRT_MEM_WRITE_ONLY 2u
+#define MIRT_MEM_READ_ONLY 4u
+
+/* ---- platform / device: webcl.getPlatforms(), platform.getDevices(), device.getInfo()
+ *      (A10 code.js:483-498, 623-631) ------------------------------------------------- */
+MIRT_API int mirt_device_count(void);
+MIRT_API int mirt_device_name(int device, char* out, size_t cap);
+MIRT_API const char* mirt_version(void);
+
+/* ---- context + command queue: webcl.createContext(device) + ctx.createCommandQueue()
+ *      (A10 code.js:582, 592); release() of both (code.js:1539-1552) ------------------- */
+MIRT_API int mirt_ctx_create(int device, mirt_ctx** out);
+MIRT_API int mirt_ctx_destroy(mirt_ctx* ctx);
+/* last error text of `ctx` (or of the calling thread when ctx is NULL); never NULL */
+MIRT_API const char* mirt_last_error(mirt_ctx* ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own */
+MIRT_API int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream);
+/* queue.finish() (A10 code.js:1096, 1406, 1533) */
+MIRT_API int mirt_finish(mirt_ctx* ctx);
+
+/* ---- buffers: ctx.createBuffer(flags, bytes) (A10 code.js:1083, 1117-1118, 1149, 1175-1177,
+ *      1221-1224, 1268-1270, 1312, 1375, 1428), buffer.release() ----------------------- */
+MIRT_API int mirt_buf_create(mirt_ctx* ctx, size_t bytes, unsigned flags, mirt_buf** out);
+/* adopt device memory owned by the caller (a torch tensor's data_ptr); release() does not free it */
+MIRT_API int mirt_buf_wrap(mirt_ctx* ctx, void* device_ptr, size_t bytes, mirt_buf** out);
+MIRT_API int mirt_buf_release(mirt_buf* buf);
+MIRT_API size_t mirt_buf_size(const mirt_buf* buf);
+MIRT_API void* mirt_buf_device_ptr(const mirt_buf* buf);
+/* queue.enqueueWriteBuffer(buf, blocking, offset, nbytes, typedArray, []) (A10 code.js:1153, 1183-1185, ...) */
+MIRT_API int mirt_buf_write(mirt_buf* buf, size_t offset, size_t nbytes, const void* host, int blocking);
+/* queue.enqueueReadBuffer(buf, blocking, offset, nbytes, typedArray, []) (A10 code.js:1070, 1532) */
+MIRT_API int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* host, int blocking);
+
+/* ---- program + kernels: ctx.createProgram(src); program.build(); program.createKernel(name)
+ *      (A10 code.js:596-607, 1048, 1087, 1107, 1158, 1206, 1256, 1307, 1348, 1366, 1422, 1446,
+ *      1463, 1483).  There is no JIT: `mirt_program_check` scans the OpenCL C text the host
+ *      would have compiled and reports, for every `__kernel void NAME(`, whether a built-in
+ *      HIP kernel of that name exists; `missing` receives a comma-separated list of those
+ *      that do not (the WebCL build log).  Returns the number of missing kernels, or <0. ---- */
+MIRT_API int mirt_program_check(mirt_ctx* ctx, const char* source, char* missing, size_t cap);
+/* names: sizeofRay sizeofPoi initAcu initTrace sphereTrace triangleTrace meshTrace lightRender
+ * initShadowTrace sphereShadowTrace triangleShadowTrace sceneRender bouncePaths copyToPixel */
+MIRT_API int mirt_kernel_get(mirt_ctx* ctx, const char* name, mirt_kernel** out);
+MIRT_API int mirt_kernel_release(mirt_kernel* k);
+/* number of arguments of the kernel (WebCL kernel.getInfo(KERNEL_NUM_ARGS)) */
+MIRT_API int mirt_kernel_num_args(const mirt_kernel* k);
+/* kernel.setArg(i, typedArray): scalars are 4 bytes, float16 64 bytes, AABB 32 bytes in the
+ * host packing (min,1,max,1) (A10 code.js:610-621, 1089, 1127-1131, ...).  Size must match. */
+MIRT_API int mirt_kernel_set_arg(mirt_kernel* k, unsigned index, size_t size, const void* value);
+/* kernel.setArg(i, webclBuffer) */
+MIRT_API int mirt_kernel_set_arg_buf(mirt_kernel* k, unsigned index, mirt_buf* buf);
+/* kernel.getWorkGroupInfo(device, KERNEL_PREFERRED_WORK_GROUP_SIZE_MULTIPLE) (A10 code.js:656): 64 */
+MIRT_API int mirt_kernel_preferred_multiple(const mirt_kernel* k);
+/* queue.enqueueNDRangeKernel(kernel, dim, null, globalWS, localWS) (A10 code.js:1095, 1302, 1330,
+ * 1339, 1343, 1399, 1405, 1414, 1503, 1507, 1511, 1519, 1527).  `local` may be NULL. */
+MIRT_API int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* global, const size_t* local);
+
+/* ---- extension: the whole pass in one launch -------------------------------------------
+ * One call == one executeRender() of the reference minus the read-back (A10 code.js:1806-1854):
+ * initTrace, closest hits, lightRender, per-light shadow + shade, `bounces` bounce segments,
+ * accumulated into `acu`; optionally followed by copyToPixel.  Results are bit-identical to
+ * enqueueing the fourteen kernels one by one.  Rows [row0, row0+nrows) of the image are
+ * rendered; seeds/acu/pixel/radiance are tile-local (nrows*width[*rpp] elements), ray ids
+ * stay global so a frame does not depend on how it is tiled over GPUs. */
+#define MIRT_MAX_LIGHTS 8
+#define MIRT_MAX_MESHES 16
+
+typedef struct mirt_grid {          /* one cell-sorted primitive set as the host uploads it        */
+    mirt_buf* prims;                /* spheres: float4 (c, r^2) | triangles: 3 x float4 positions  */
+    mirt_buf* normals;              /* triangles: 3 x float4 normals; NULL for spheres             */
+    mirt_buf* matid;                /* uint per primitive; NULL for a mesh (uses mesh_matid)       */
+    mirt_buf* cell_offsets;         /* uint[n^3 + 1]                                               */
+    float bounds[8];                /* (min,1,max,1), bounds2AABB, A10 code.js:610-621             */
+    uint32_t n_slabs;
+    uint32_t mesh_matid;
+} mirt_grid;
+
+typedef struct mirt_light {         /* Light.to{Shadow,SceneRender,LightRender}Info, A10 code.js:323-352 */
+    float shadow[16];
+    float scene[16];
+    float light[16];
+} mirt_light;
+
+typedef struct mirt_pass_desc {
+    uint32_t struct_size;           /* sizeof(mirt_pass_desc), for ABI evolution                   */
+    uint32_t width, height, rays_per_pixel;
+    uint32_t row0, nrows;           /* row tile; nrows == 0 means the whole image                  */
+    uint32_t bounces;               /* 5 == reference (A10 code.js:1829)                           */
+    uint32_t pass_index;            /* 1-based `passes` counter (A10 code.js:1850)                 */
+    float cam[16];                  /* Camera.toFloat32Array, A10 code.js:250-258                  */
+    float scene_bounds[8];
+    float focal_length, lens_rad;   /* A10 code.js:1129-1130 (lens_rad = lens_diameter/2)          */
+    uint32_t n_lights, n_meshes;
+    const mirt_grid* spheres;       /* NULL: none                                                  */
+    const mirt_grid* triangles;     /* NULL: none                                                  */
+    const mirt_grid* meshes;        /* [n_meshes]                                                  */
+    const mirt_light* lights;       /* [n_lights]                                                  */
+    mirt_buf* material;             /* float4 per material (splitMaterialData, code.js:1774-1782)  */
+    mirt_buf* seeds;                /* int32 per local ray, read-modify-write                      */
+    mirt_buf* acu;                  /* float4 per local ray, accumulated into (zero it first)      */
+    mirt_buf* pixel;                /* optional: uchar4 per local pixel, written by copyToPixel    */
+    mirt_buf* radiance;             /* optional: float4 per local pixel, un-scaled sequential sums */
+} mirt_pass_desc;
+
+MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
+
+/* seeds[i] = 1 + (mix32((first_ray + i) ^ 0x9E3779B9 ^ seed_base) mod 2147483646): the
+ * reproducible stand-in for the host's Math.random() seeding (A10 code.js:1140-1146). */
+MIRT_API int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, uint64_t count, uint32_t seed_base);
+/* initAcu over a whole buffer (A10 code.js:1078-1099) */
+MIRT_API int mirt_zero(mirt_ctx* ctx, mirt_buf* buf);
+
+/* ---- diagnostics: evaluate one primitive of the numerics contract element-wise on the device
+ * (op: 0 a/b, 1 sqrt, 2 sin, 3 cos, 4 getRand(seed=bits of a), 5 next LCG state, 6 min, 7 max,
+ * 8 fmin, 9 fmax, 10 normalize(a,b,1).x, 11/12 concentric_distort(a,b).x/.y, 13 (int)a).
+ * Lets a test compare device bits with host bits over millions of inputs. ---------------- */
+MIRT_API int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n);
+
+/* ---- measurement: HIP events on the context's stream ---------------------------------- */
+MIRT_API int mirt_timer_start(mirt_ctx* ctx);
+MIRT_API int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms);   /* synchronises */
+/* per-kernel events inside mirt_render_pass: duration of the fused pass kernel and of the resolve
+ * (copyToPixel) kernel of the most recent profiled pass, on the stream they were launched on */
+MIRT_API int mirt_ctx_set_profiling(mirt_ctx* ctx, int on);
+MIRT_API int mirt_pass_timing(mirt_ctx* ctx, float* fused_ms, float* resolve_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */

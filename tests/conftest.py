@@ -1,0 +1,61 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+FULL_CASES = [
+    "basic_64x48_r1", "basic_32x24_r4", "triangles_64x48_r1", "triangles_32x24_r4",
+    "cornell_64x48_r1", "cornell_32x24_r4", "cornell_16x12_r9",
+    "cornell_teapot3_64x48_r1", "cornell_teapot3_32x24_r4", "cornell_official_64x48_r1",
+    "twoLights_32x24_r4", "threeLights_32x24_r1",
+]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def load_fixture(name):
+    import a10_pass as A
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sc = A.Scene(json.loads(bytes(fx["scene_json"]).decode()))
+    return fx, sc
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def assert_state_equal(tag, got, fx, prefix):
+    """Compare a pass state (dict of numpy views: rays/shadow/pois structured, acu, seeds) with a fixture
+    bit for bit.  Fields the reference leaves undefined are masked: o/d of dead rays (only mint/maxt are
+    written, A10 code.cl:595, 647) and p/normal of vertices that were never hit."""
+    assert np.array_equal(bits(got["acu"]).reshape(-1, 4), bits(fx[f"{prefix}_acu"])), f"{tag}: acu"
+    assert np.array_equal(got["seeds"], fx[f"{prefix}_seeds"]), f"{tag}: seeds"
+    for k in ("rays", "shadow"):
+        for f in ("mint", "maxt"):
+            assert np.array_equal(bits(got[k][f]), bits(fx[f"{prefix}_{k}_{f}"])), f"{tag}: {k}.{f}"
+        # dead rays (mint == maxt == inf written by bouncePaths/initShadowTrace/lightRender) have undefined o/d
+        live = ~(np.isinf(fx[f"{prefix}_{k}_mint"]) & np.isinf(fx[f"{prefix}_{k}_maxt"]))
+        for f in ("o", "d"):
+            assert np.array_equal(bits(got[k][f][live]), bits(fx[f"{prefix}_{k}_{f}"][live])), f"{tag}: {k}.{f}"
+    assert np.array_equal(got["pois"]["matId"], fx[f"{prefix}_pois_matId"]), f"{tag}: matId"
+    assert np.array_equal(bits(got["pois"]["atte"]), bits(fx[f"{prefix}_pois_atte"])), f"{tag}: atte"
+    hit = fx[f"{prefix}_pois_matId"] >= 0
+    for f in ("p", "normal"):
+        assert np.array_equal(bits(got["pois"][f][hit]), bits(fx[f"{prefix}_pois_{f}"][hit])), f"{tag}: pois.{f}"
