@@ -59,6 +59,10 @@ struct mirt_buf {
     uint64_t off_version = 0;
     uint32_t off_n = 0;
     uint32_t off_last = 0;
+    // prepared-triangle copy of a position buffer (fused path), rebuilt when the contents change
+    void* prep = nullptr;
+    size_t prep_bytes = 0;
+    uint64_t prep_version = 0;
 };
 
 enum ArgType { A_BUF, A_U32, A_F32, A_F16, A_AABB };
@@ -289,6 +293,11 @@ int mirt_buf_release(mirt_buf* buf) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(buf->ptr);
+    }
+    if (buf->prep && live_has(ctx)) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(buf->prep);
     }
     delete buf;
     return MIRT_OK;
@@ -564,6 +573,19 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
                         per_prim_matid ? g->matid : nullptr);
     if (rc) return rc;
     o->prims = g->prims->ptr;
+    o->kind = tri ? pt::KIND_TRIANGLES : pt::KIND_SPHERES;
+    if (tri) {
+        mirt_buf* pb = g->prims;
+        const uint32_t count = g->cell_offsets->off_last;
+        const size_t bytes = (size_t)count * 48;
+        if (pb->prep_version != pb->version || pb->prep_bytes < bytes) {
+            if (pb->prep) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pb->prep)); pb->prep = nullptr; pb->prep_bytes = 0; }
+            if (bytes) { HIPCHK(ctx, hipMalloc(&pb->prep, bytes)); pb->prep_bytes = bytes; }
+            pt::launch_prepTriangles(ctx->stream, pb->ptr, pb->prep, count);
+            pb->prep_version = pb->version;
+        }
+        o->prims = pb->prep ? pb->prep : pb->ptr;
+    }
     o->normals = tri ? g->normals->ptr : nullptr;
     o->matid = per_prim_matid ? g->matid->ptr : nullptr;
     o->off = g->cell_offsets->ptr;
@@ -597,12 +619,12 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
     A.focal_length = d->focal_length; A.lens_rad = d->lens_rad;
     A.width = d->width; A.height = d->height; A.rpp = d->rays_per_pixel;
     A.row0 = d->row0; A.nrows = nrows; A.bounces = d->bounces;
-    A.n_lights = d->n_lights; A.n_meshes = d->n_meshes;
+    A.n_lights = d->n_lights;
     int rc;
-    if (d->spheres) { A.has_spheres = 1; if ((rc = fill_grid(ctx, "spheres", d->spheres, false, true, &A.spheres))) return rc; }
-    if (d->triangles) { A.has_triangles = 1; if ((rc = fill_grid(ctx, "triangles", d->triangles, true, true, &A.triangles))) return rc; }
+    if (d->spheres && (rc = fill_grid(ctx, "spheres", d->spheres, false, true, &A.sets[A.n_sets++]))) return rc;
+    if (d->triangles && (rc = fill_grid(ctx, "triangles", d->triangles, true, true, &A.sets[A.n_sets++]))) return rc;
     for (uint32_t m = 0; m < d->n_meshes; ++m)
-        if ((rc = fill_grid(ctx, "mesh", &d->meshes[m], true, false, &A.meshes[m]))) return rc;
+        if ((rc = fill_grid(ctx, "mesh", &d->meshes[m], true, false, &A.sets[A.n_sets++]))) return rc;
     for (uint32_t l = 0; l < d->n_lights; ++l) {
         memcpy(A.lights[l].shadow, d->lights[l].shadow, 64);
         memcpy(A.lights[l].scene, d->lights[l].scene, 64);

@@ -133,21 +133,24 @@ PT_DEV bool slab1(float lo, float hi, float o, float d, BoxHit& h) {
     return !(h.tmin > h.tmax);
 }
 PT_DEV BoxHit inter_aabb(const Ray& r, const Box& b) {
+    // The reference returns at the first slab with tmin > tmax (code.cl:351-354, 366-369,
+    // 381-384); the later slabs only refine values nobody reads after a failure, so all
+    // three are evaluated here and the verdicts and-ed: same `v`, same tmin/tmax when v.
     BoxHit h;
     h.tmin = 0.0f;
     h.tmax = PT_INF;
-    h.v = false;
-    if (!slab1(b.lo.x, b.hi.x, r.o.x, r.d.x, h)) return h;
-    if (!slab1(b.lo.y, b.hi.y, r.o.y, r.d.y, h)) return h;
-    if (!slab1(b.lo.z, b.hi.z, r.o.z, r.d.z, h)) return h;
-    h.v = true;
+    const bool okx = slab1(b.lo.x, b.hi.x, r.o.x, r.d.x, h);
+    const bool oky = slab1(b.lo.y, b.hi.y, r.o.y, r.d.y, h);
+    const bool okz = slab1(b.lo.z, b.hi.z, r.o.z, r.d.z, h);
+    h.v = okx && oky && okz;
     return h;
 }
 // primary-ray clip of initTrace (code.cl:494-501): miss -> mint = maxt ("dead ray")
 PT_DEV void clip_to(Ray& r, const Box& b) {
     BoxHit h = inter_aabb(r, b);
-    if (h.v) { r.mint = h.tmin; r.maxt = h.tmax; }
-    else { r.mint = r.maxt; }
+    const float far_ = r.maxt;
+    r.mint = h.v ? h.tmin : far_;
+    r.maxt = h.v ? h.tmax : far_;
 }
 
 // ---- primitives ------------------------------------------------------------------------

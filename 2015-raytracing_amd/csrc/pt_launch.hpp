@@ -33,13 +33,15 @@ constexpr int kMaxLights = 8;
 constexpr int kMaxMeshes = 16;
 
 struct GridArgs {            // one cell-sorted primitive set, device pointers
-    const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per triangle
+    const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per PREPARED triangle (launch_prepTriangles)
     const void* normals;     // 3 x float4 per triangle (null for spheres)
     const void* matid;       // uint per primitive (null: use `mesh_matid`)
     const void* off;         // uint[n^3 + 1]
     float bound[8];          // (min,1,max,1)
     uint32_t n;              // cells per axis
     uint32_t mesh_matid;
+    uint32_t kind;           // KIND_SPHERES | KIND_TRIANGLES
+    uint32_t _pad;
 };
 struct LightArgs {           // the three float16 packings of one light (A10 code.js:323-352)
     float shadow[16];        // pos, T, B, radius
@@ -53,9 +55,8 @@ struct FusedArgs {
     uint32_t width, height, rpp;
     uint32_t row0, nrows;    // row tile this launch renders; per-ray buffers are tile-local
     uint32_t bounces;        // 5 in the reference (A10 code.js:1829)
-    uint32_t has_spheres, has_triangles, n_meshes, n_lights;
-    GridArgs spheres, triangles;
-    GridArgs meshes[kMaxMeshes];
+    uint32_t n_sets, n_lights;
+    GridArgs sets[2 + kMaxMeshes];   // upload order: spheres, loose triangles, mesh 0..M-1 (A10 code.js:1809-1813)
     LightArgs lights[kMaxLights];
     const void* material;    // float4[nmat]
     uint32_t nmat;
@@ -64,5 +65,7 @@ struct FusedArgs {
     const void* uv;          // rpp == 1: float2[nrows*width] lens draws from launch_lensDraws
 };
 void launch_fused(hipStream_t s, const FusedArgs& a);
+// {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip)
+void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count);
 
 }  // namespace pt
