@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds mirt.node (N-API addon over libmirt.so) next to libmirt.so.  Needs the Node headers
+# (/usr/include/node in this image); skipped with a note when they are absent.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+PKG="${HERE}/../.."
+INC="${NODE_INCLUDE:-/usr/include/node}"
+if [ ! -f "${INC}/node_api.h" ]; then echo "node_api.h not found under ${INC}: mirt.node not built"; exit 0; fi
+g++ -std=c++17 -O2 -fPIC -shared -Wall -Wextra -Wno-unused-parameter -DNODE_GYP_MODULE_NAME=mirt -I"${INC}" \
+    -o "${PKG}/mirt.node" "${HERE}/mirt_napi.cc" -L"${PKG}" -lmirt -Wl,-rpath,'$ORIGIN'
+echo "built ${PKG}/mirt.node"

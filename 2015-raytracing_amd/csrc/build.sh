@@ -4,7 +4,7 @@
 #   -fhip-fp32-correctly-rounded-divide-sqrt : the hipcc default, spelled out because parity depends on it
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="${HERE}/../libmirt.so"
+OUT="${MIRT_OUT:-${HERE}/../libmirt.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden
        -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt

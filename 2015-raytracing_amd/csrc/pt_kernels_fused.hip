@@ -242,7 +242,10 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc)
     }
 }
 
-__global__ void __launch_bounds__(256) k_fusedPass(const FusedArgs A) {
+#ifndef PT_FUSED_WAVES
+#define PT_FUSED_WAVES 4   // waves per SIMD the register allocator must leave room for
+#endif
+__global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedArgs A) {
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;
     const uint64_t lid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lid >= n_local) return;

@@ -1,0 +1,43 @@
+#!/usr/bin/env node
+// host/cli.js -- command-line front end of the JavaScript host.
+//   node cli.js pack   <scene.xml> <width> <height> <raysPerPixel>                 -> packed kernel inputs as JSON (stdout)
+//   node cli.js render <scene.xml> <width> <height> <raysPerPixel> <passes> <out.rgba> [--granular] [--bounces N] [--seeds file.i32]
+//                                                                                   -> RGBA8 frame (+ <out>.radiance.f32) via the N-API addon
+//   node cli.js devices                                                             -> what webcl.getPlatforms()/getDevices() report
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const scene = require("./scene.js");
+
+function usage() {
+  process.stderr.write(fs.readFileSync(__filename, "utf8").split("\n").slice(1, 8).join("\n") + "\n");
+  process.exit(2);
+}
+
+const [cmd, ...rest] = process.argv.slice(2);
+if (cmd === "pack") {
+  if (rest.length < 4) usage();
+  const [file, w, h, rpp] = [rest[0], +rest[1], +rest[2], +rest[3]];
+  const sc = scene.loadSceneFile(file, w, h);
+  const p = scene.packedToJSON(scene.packScene(sc, w, h, rpp));
+  p.scene = path.basename(file);
+  process.stdout.write(JSON.stringify(p));
+} else if (cmd === "render") {
+  if (rest.length < 6) usage();
+  const renderer = require("./renderer.js");
+  const opt = { granular: rest.includes("--granular"), bounces: 5, seeds: null };
+  let i;
+  if ((i = rest.indexOf("--bounces")) >= 0) opt.bounces = +rest[i + 1];
+  if ((i = rest.indexOf("--seeds")) >= 0) { const b = fs.readFileSync(rest[i + 1]); opt.seeds = new Int32Array(b.buffer, b.byteOffset, b.length / 4); }
+  const [file, w, h, rpp, passes, out] = [rest[0], +rest[1], +rest[2], +rest[3], +rest[4], rest[5]];
+  const res = renderer.renderFile(file, w, h, rpp, passes, opt);
+  fs.writeFileSync(out, Buffer.from(res.pixel.buffer, res.pixel.byteOffset, res.pixel.byteLength));
+  fs.writeFileSync(out + ".radiance.f32", Buffer.from(res.radiance.buffer, res.radiance.byteOffset, res.radiance.byteLength));
+  process.stderr.write(`rendered ${file} ${w}x${h} rpp ${rpp}, ${passes} pass(es), ${opt.granular ? "kernel-by-kernel" : "fused"}: ${res.ms.toFixed(2)} ms on ${res.device}\n`);
+} else if (cmd === "devices") {
+  const { webcl } = require("./webcl.js");
+  for (const p of webcl.getPlatforms()) {
+    console.log(p.getInfo(webcl.PLATFORM_NAME), "|", p.getInfo(webcl.PLATFORM_VENDOR), "|", p.getInfo(webcl.PLATFORM_VERSION));
+    for (const d of p.getDevices(webcl.DEVICE_TYPE_ALL)) console.log("  device:", d.getInfo(webcl.DEVICE_NAME));
+  }
+} else usage();

@@ -1,0 +1,243 @@
+// host/renderer.js -- the render drivers of the JavaScript host.
+//
+// GranularRenderer is the reference's kernel plumbing, call for call: preRender() and
+// executeRender() of A10 code.js:1784-1854 with the prepare*/execute* helpers (:1078-1528),
+// written against the WebCL-shaped API of ./webcl.js -- same kernels, same argument indices,
+// same enqueue order, same NDRange padding.  FusedRenderer asks the runtime for the same pass
+// in one launch (queue.renderPass).  Both produce bit-identical frames.
+"use strict";
+const { webcl } = require("./webcl.js");
+const scene = require("./scene.js");
+
+const KERNELS = ["sizeofRay", "sizeofPoi", "initAcu", "initTrace", "sphereTrace", "triangleTrace", "meshTrace", "lightRender",
+                 "initShadowTrace", "sphereShadowTrace", "triangleShadowTrace", "sceneRender", "bouncePaths", "copyToPixel"];
+// what createProgram() is given in place of code.cl: the list of kernels this host will ask for
+const MANIFEST = KERNELS.map((k) => "__kernel void " + k + "();").join("\n");
+
+const u32 = (v) => new Uint32Array([v]);
+const f32 = (v) => new Float32Array([v]);
+const ceilTo = (n, m) => Math.ceil(n / m) * m;
+
+function getLocalWS(dim, kernel, device) {  // code.js:645-672
+  const m = kernel.getWorkGroupInfo(device, webcl.KERNEL_PREFERRED_WORK_GROUP_SIZE_MULTIPLE);
+  if (dim === 1) return [m];
+  let x = Math.floor(Math.sqrt(m));
+  if (x & (x - 1)) { --x; for (let i = 1; i < 32; i <<= 1) x |= x >> i; ++x; }
+  return [x, Math.floor(m / x)];
+}
+
+function pickDevice(index) {
+  const devs = webcl.getPlatforms()[0].getDevices(webcl.DEVICE_TYPE_ALL);
+  if (!devs.length) throw new Error("no MI355X visible: this host has no CPU path");
+  return devs[index || 0];
+}
+
+// uploads the packed scene (scene.packScene) the way prepare*() do (code.js:1175-1185, 1221-1234, 1268-1278, 1375-1379)
+function uploadScene(ctx, q, p) {
+  const up = (a) => { const b = ctx.createBuffer(webcl.MEM_READ_ONLY, Math.max(a.byteLength, 16)); if (a.byteLength) q.enqueueWriteBuffer(b, false, 0, a.byteLength, a, []); return b; };
+  const d = { bufs: [] };
+  const keep = (b) => { d.bufs.push(b); return b; };
+  if (p.n_spheres > 0) d.sph = { prims: keep(up(p.spheres)), matid: keep(up(p.s_matid)), cellOffsets: keep(up(p.s_box)), bounds: p.sphere_bounds, nSlabs: p.n_slabs };
+  if (p.n_triangles > 0) d.tri = { prims: keep(up(p.t_pos)), normals: keep(up(p.t_normal)), matid: keep(up(p.t_matid)), cellOffsets: keep(up(p.t_box)), bounds: p.triangle_bounds, nSlabs: p.n_slabs };
+  d.meshes = p.meshes.map((m) => ({ prims: keep(up(m.pos)), normals: keep(up(m.normal)), cellOffsets: keep(up(m.box)), bounds: m.bounds, nSlabs: m.nslabs, meshMatId: m.matid }));
+  d.material = keep(up(p.materials));
+  return d;
+}
+
+class GranularRenderer {
+  constructor(packed, opt) {
+    opt = opt || {};
+    this.p = packed;
+    this.device = pickDevice(opt.device);
+    this.ctx = webcl.createContext(this.device);           // createCLBasicResources (code.js:576-608)
+    this.q = this.ctx.createCommandQueue();
+    this.program = this.ctx.createProgram(MANIFEST);
+    this.program.build();
+    this.k = {}; this.b = {}; this.gws = {}; this.lws = {};
+    this.passes = 1;
+    this._preRender(opt.seeds, opt.seedBase);
+  }
+  _structSize(name) {  // getStructSize (code.js:1064-1076)
+    const k = this.program.createKernel("sizeof" + name), b = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, 4), out = new Uint32Array(1);
+    k.setArg(0, b);
+    this.q.enqueueNDRangeKernel(k, 1, null, [1], [1]);
+    this.q.enqueueReadBuffer(b, false, 0, 4, out, []);
+    this.q.finish();
+    b.release(); k.release();
+    return out[0];
+  }
+  _preRender(seeds, seedBase) {
+    const p = this.p, ctx = this.ctx, q = this.q, prog = this.program, k = this.k, b = this.b;
+    const n = this.totalRays = p.rays_per_pixel * p.width * p.height;
+    // prepareInitAcu
+    b.acu = ctx.createBuffer(webcl.MEM_READ_WRITE, n * 16);
+    const ia = prog.createKernel("initAcu");
+    ia.setArg(0, b.acu); ia.setArg(1, u32(n));
+    let l = getLocalWS(1, ia, this.device);
+    q.enqueueNDRangeKernel(ia, 1, null, [ceilTo(n, l[0])], l);
+    q.finish(); ia.release();
+    // prepareInitSeeds: Math.random() in the reference; a caller-supplied array or the device-side closed form here
+    b.seeds = ctx.createBuffer(webcl.MEM_READ_WRITE, n * 4);
+    if (seeds) q.enqueueWriteBuffer(b.seeds, false, 0, n * 4, seeds, []); else q.seedFill(b.seeds, 0, n, seedBase || 0);
+    // prepareInitTrace
+    const raySize = this._structSize("Ray"), poiSize = this._structSize("Poi");
+    b.rays = ctx.createBuffer(webcl.MEM_READ_WRITE, n * raySize);
+    b.pois = ctx.createBuffer(webcl.MEM_READ_WRITE, n * poiSize);
+    k.initTrace = prog.createKernel("initTrace");
+    [b.seeds, b.rays, b.pois, p.bounds].forEach((v, i) => k.initTrace.setArg(i, v));
+    k.initTrace.setArg(5, f32(p.focal_length)); k.initTrace.setArg(6, f32(p.lens_rad)); k.initTrace.setArg(7, u32(p.rays_per_pixel));
+    l = this.lws.initTrace = getLocalWS(2, k.initTrace, this.device);
+    this.gws.initTrace = [ceilTo(p.width, l[0]), ceilTo(p.height, l[1])];
+    const d = this.dev = uploadScene(ctx, q, p);
+    if (d.sph) {  // prepareSphereTrace
+      k.sphereTrace = prog.createKernel("sphereTrace");
+      [u32(n), b.pois, b.rays, d.sph.prims, d.sph.matid, d.sph.cellOffsets, d.sph.bounds, u32(d.sph.nSlabs)].forEach((v, i) => k.sphereTrace.setArg(i, v));
+    }
+    if (d.tri) {  // prepareTriangleTrace
+      k.triangleTrace = prog.createKernel("triangleTrace");
+      [u32(n), b.pois, b.rays, d.tri.prims, d.tri.normals, d.tri.matid, d.tri.cellOffsets, d.tri.bounds, u32(d.tri.nSlabs)].forEach((v, i) => k.triangleTrace.setArg(i, v));
+    }
+    if (d.meshes.length) {  // prepareMeshTrace
+      k.meshTrace = prog.createKernel("meshTrace");
+      [u32(n), b.pois, b.rays].forEach((v, i) => k.meshTrace.setArg(i, v));
+    }
+    // prepareInitShadowTrace
+    b.shadow = ctx.createBuffer(webcl.MEM_READ_WRITE, n * raySize);
+    k.initShadowTrace = prog.createKernel("initShadowTrace");
+    k.initShadowTrace.setArg(0, b.shadow); k.initShadowTrace.setArg(1, b.pois); k.initShadowTrace.setArg(2, u32(n)); k.initShadowTrace.setArg(4, b.seeds);
+    if (d.sph) {
+      k.sphereShadowTrace = prog.createKernel("sphereShadowTrace");
+      [u32(n), b.shadow, d.sph.prims, d.sph.cellOffsets, d.sph.bounds, u32(d.sph.nSlabs)].forEach((v, i) => k.sphereShadowTrace.setArg(i, v));
+    }
+    if (d.tri || d.meshes.length) {
+      k.triangleShadowTrace = prog.createKernel("triangleShadowTrace");
+      k.triangleShadowTrace.setArg(0, u32(n)); k.triangleShadowTrace.setArg(1, b.shadow);
+    }
+    // prepareSceneRender / prepareCopyToPixel / prepareBouncePaths / prepareLightRender
+    k.sceneRender = prog.createKernel("sceneRender");
+    [b.acu, b.pois, b.shadow, d.material].forEach((v, i) => k.sceneRender.setArg(i, v));
+    k.sceneRender.setArg(5, u32(n));
+    const npix = p.width * p.height;
+    b.pixel = ctx.createBuffer(webcl.MEM_WRITE_ONLY, npix * 4);
+    k.copyToPixel = prog.createKernel("copyToPixel");
+    k.copyToPixel.setArg(0, b.pixel); k.copyToPixel.setArg(1, b.acu); k.copyToPixel.setArg(3, u32(npix)); k.copyToPixel.setArg(4, u32(p.rays_per_pixel));
+    this.gws.copyToPixel = [ceilTo(npix, 64)];
+    k.bouncePaths = prog.createKernel("bouncePaths");
+    [b.pois, b.rays, b.seeds, u32(n)].forEach((v, i) => k.bouncePaths.setArg(i, v));
+    k.lightRender = prog.createKernel("lightRender");
+    k.lightRender.setArg(0, b.pois); k.lightRender.setArg(1, b.rays); k.lightRender.setArg(2, b.acu); k.lightRender.setArg(4, u32(n));
+    this.g1 = [ceilTo(n, 64)];
+  }
+  _run(kernel) { this.q.enqueueNDRangeKernel(kernel, 1, null, this.g1, [64]); }
+  _closest() {
+    const k = this.k, d = this.dev;
+    if (d.sph) this._run(k.sphereTrace);
+    if (d.tri) this._run(k.triangleTrace);
+    for (const m of d.meshes) {  // executeMeshTrace (code.js:1293-1303)
+      k.meshTrace.setArg(3, m.prims); k.meshTrace.setArg(4, m.normals); k.meshTrace.setArg(5, m.cellOffsets);
+      k.meshTrace.setArg(6, u32(m.meshMatId)); k.meshTrace.setArg(7, m.bounds); k.meshTrace.setArg(8, u32(m.nSlabs));
+      this._run(k.meshTrace);
+    }
+  }
+  _direct() {
+    const k = this.k, d = this.dev;
+    for (const light of this.p.lights) {
+      k.initShadowTrace.setArg(3, light.shadow); this._run(k.initShadowTrace);
+      if (d.sph) this._run(k.sphereShadowTrace);
+      const sets = (d.tri ? [d.tri] : []).concat(d.meshes);  // executeTriangleShadowTrace / executeMeshShadowTrace (code.js:1514-1528)
+      for (const s of sets) {
+        k.triangleShadowTrace.setArg(2, s.prims); k.triangleShadowTrace.setArg(3, s.cellOffsets); k.triangleShadowTrace.setArg(4, s.bounds);
+        k.triangleShadowTrace.setArg(5, u32(s.nSlabs)); this._run(k.triangleShadowTrace);
+      }
+      k.sceneRender.setArg(4, light.scene); this._run(k.sceneRender);  // executeSceneRender (code.js:1402-1408)
+      this.q.finish();
+    }
+  }
+  executeRender(bounces) {  // code.js:1806-1854
+    const k = this.k, p = this.p;
+    k.initTrace.setArg(4, p.cam);
+    this.q.enqueueNDRangeKernel(k.initTrace, 2, null, this.gws.initTrace, this.lws.initTrace);
+    this._closest();
+    for (const light of p.lights) { k.lightRender.setArg(3, light.light); this._run(k.lightRender); }
+    this._direct();
+    for (let j = 0; j < (bounces === undefined ? 5 : bounces); j++) { this._run(k.bouncePaths); this._closest(); this._direct(); }
+    k.copyToPixel.setArg(2, f32(1.0 / (p.rays_per_pixel * this.passes)));  // executeCopyToPixel (code.js:1410-1415)
+    this.q.enqueueNDRangeKernel(k.copyToPixel, 1, null, this.gws.copyToPixel, [64]);
+    this.passes++;
+  }
+  readPixels() {  // sendImagetoHTML (code.js:1530-1537)
+    const out = new Uint8ClampedArray(this.p.width * this.p.height * 4);
+    this.q.enqueueReadBuffer(this.b.pixel, false, 0, out.length, out, []);
+    this.q.finish();
+    return out;
+  }
+  readAcu() { const a = new Float32Array(this.totalRays * 4); this.q.enqueueReadBuffer(this.b.acu, false, 0, a.byteLength, a, []); this.q.finish(); return a; }
+  release() {  // releaseCLResources (code.js:1539-1552)
+    Object.values(this.k).forEach((k) => k.release());
+    Object.values(this.b).forEach((b) => b.release());
+    this.dev.bufs.forEach((b) => b.release());
+    this.program.release(); this.q.release(); this.ctx.release();
+  }
+}
+
+class FusedRenderer {
+  constructor(packed, opt) {
+    opt = opt || {};
+    const p = this.p = packed;
+    this.device = pickDevice(opt.device);
+    this.ctx = webcl.createContext(this.device);
+    this.q = this.ctx.createCommandQueue();
+    this.row0 = opt.row0 || 0;
+    this.nrows = opt.nrows || p.height;
+    this.npix = this.nrows * p.width;
+    this.nrays = this.npix * p.rays_per_pixel;
+    const first = this.row0 * p.width * p.rays_per_pixel;
+    this.dev = uploadScene(this.ctx, this.q, p);
+    this.seeds = this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 4);
+    if (opt.seeds) this.q.enqueueWriteBuffer(this.seeds, false, 0, this.nrays * 4, opt.seeds.subarray(first, first + this.nrays), []);
+    else this.q.seedFill(this.seeds, first, this.nrays, opt.seedBase || 0);
+    this.acu = this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 16);
+    this.q.zero(this.acu);
+    this.pixel = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, this.npix * 4);
+    this.radiance = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, this.npix * 16);
+    this.passes = 1;
+  }
+  executeRender(bounces) {
+    const p = this.p, d = this.dev;
+    this.q.renderPass({ width: p.width, height: p.height, raysPerPixel: p.rays_per_pixel, row0: this.row0, nrows: this.nrows,
+      bounces: bounces === undefined ? 5 : bounces, passIndex: this.passes, cam: p.cam, sceneBounds: p.bounds,
+      focalLength: p.focal_length, lensRad: p.lens_rad, spheres: d.sph, triangles: d.tri, meshes: d.meshes, lights: p.lights,
+      material: d.material, seeds: this.seeds, acu: this.acu, pixel: this.pixel, radiance: this.radiance });
+    this.passes++;
+  }
+  readPixels() { const o = new Uint8ClampedArray(this.npix * 4); this.q.enqueueReadBuffer(this.pixel, false, 0, o.length, o, []); this.q.finish(); return o; }
+  readRadiance() { const o = new Float32Array(this.npix * 4); this.q.enqueueReadBuffer(this.radiance, false, 0, o.byteLength, o, []); this.q.finish(); return o; }
+  readAcu() { const a = new Float32Array(this.nrays * 4); this.q.enqueueReadBuffer(this.acu, false, 0, a.byteLength, a, []); this.q.finish(); return a; }
+  release() {
+    [this.seeds, this.acu, this.pixel, this.radiance].forEach((b) => b.release());
+    this.dev.bufs.forEach((b) => b.release());
+    this.q.release(); this.ctx.release();
+  }
+}
+
+// per-pixel sequential fp32 sums of the per-ray accumulators (copyToPixel's order, A10 code.cl:1377-1380)
+function radianceSums(acu, rpp) {
+  const n = acu.length / 4 / rpp, out = new Float32Array(n * 4);
+  for (let px = 0; px < n; px++) for (let i = 0; i < rpp; i++) for (let c = 0; c < 4; c++) out[4 * px + c] = Math.fround(out[4 * px + c] + acu[4 * (px * rpp + i) + c]);
+  return out;
+}
+
+function renderFile(file, width, height, rpp, passes, opt) {
+  opt = opt || {};
+  const packed = scene.packScene(scene.loadSceneFile(file, width, height), width, height, rpp);
+  const R = opt.granular ? new GranularRenderer(packed, opt) : new FusedRenderer(packed, opt);
+  R.q.timerStart();
+  for (let i = 0; i < passes; i++) R.executeRender(opt.bounces);
+  const ms = R.q.timerStopMs();
+  const res = { pixel: R.readPixels(), radiance: opt.granular ? radianceSums(R.readAcu(), rpp) : R.readRadiance(), ms: ms,
+                device: R.device.getInfo(webcl.DEVICE_NAME) };
+  R.release();
+  return res;
+}
+
+module.exports = { GranularRenderer, FusedRenderer, renderFile, radianceSums, getLocalWS, KERNELS };

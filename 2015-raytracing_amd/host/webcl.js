@@ -1,0 +1,178 @@
+// host/webcl.js -- the WebCL 1.0 object model the reference host drives, backed by the MI355X
+// runtime (mirt.node -> libmirt.so -> hand-written HIP kernels).
+//
+// Only what the ten code.js files of the reference touch is implemented (SURVEY.md 8b), with the
+// reference's call shapes:
+//   webcl.getPlatforms() -> platform.getInfo(PLATFORM_*), platform.getDevices(DEVICE_TYPE_ALL)
+//   device.getInfo(DEVICE_NAME | DEVICE_TYPE)                          A10 code.js:483-498, 623-631
+//   webcl.createContext(device) -> ctx.createCommandQueue()            :582, 592
+//   ctx.createProgram(src); program.build(); program.getBuildInfo()    :596-606
+//   program.createKernel(name); kernel.setArg(i, buffer | typedArray)  :1087-1089, 1124-1131, ...
+//   kernel.getWorkGroupInfo(device, KERNEL_PREFERRED_WORK_GROUP_SIZE_MULTIPLE)   :656
+//   ctx.createBuffer(flags, bytes)                                     :1083, 1117-1118, ...
+//   queue.enqueueWriteBuffer / enqueueReadBuffer / enqueueNDRangeKernel / finish  :1095-1096, 1153, 1532-1533
+//   release() on everything                                            :1539-1552
+// plus one extension, queue.renderPass(desc): the whole executeRender() in one fused launch.
+//
+// There is no OpenCL compiler behind createProgram(): the kernels are built-in HIP code, looked
+// up by name.  build() scans the OpenCL C text for `__kernel void NAME(` and throws, with the
+// missing names as the build log, if the source asks for a kernel the runtime does not have.
+"use strict";
+const path = require("path");
+
+let addon = null;
+function native() {
+  if (!addon) {
+    try {
+      addon = require(path.join(__dirname, "..", "mirt.node"));
+    } catch (e) {
+      throw new Error("mirt.node is not built (python -c 'import __graft_entry__ as g; g.build()'): " + e.message);
+    }
+  }
+  return addon;
+}
+
+class WebCLException extends Error {
+  constructor(name, msg) { super(msg); this.name = name; this.code = name; }
+}
+function wrap(f) {  // native errors -> WebCL-style exceptions
+  try { return f(); } catch (e) {
+    const map = { MIRT_E_ARG: "INVALID_VALUE", MIRT_E_HANDLE: "INVALID_MEM_OBJECT", MIRT_E_NAME: "INVALID_KERNEL_NAME",
+                  MIRT_E_UNSET: "INVALID_KERNEL_ARGS", MIRT_E_RANGE: "INVALID_BUFFER_SIZE", MIRT_E_DEVICE: "OUT_OF_RESOURCES",
+                  MIRT_E_NODEVICE: "DEVICE_NOT_FOUND", MIRT_E_DATA: "INVALID_VALUE" };
+    throw new WebCLException(map[e.code] || "WEBCL_IMPLEMENTATION_FAILURE", e.message);
+  }
+}
+
+const C = {
+  // values follow the OpenCL 1.1 / WebCL 1.0 enumerants
+  PLATFORM_PROFILE: 0x0900, PLATFORM_VERSION: 0x0901, PLATFORM_NAME: 0x0902, PLATFORM_VENDOR: 0x0903, PLATFORM_EXTENSIONS: 0x0904,
+  DEVICE_TYPE_CPU: 2, DEVICE_TYPE_GPU: 4, DEVICE_TYPE_ALL: 0xFFFFFFFF, DEVICE_TYPE: 0x1000, DEVICE_NAME: 0x102B,
+  MEM_READ_WRITE: 1, MEM_WRITE_ONLY: 2, MEM_READ_ONLY: 4,
+  PROGRAM_BUILD_STATUS: 0x1181, PROGRAM_BUILD_LOG: 0x1183, BUILD_SUCCESS: 0, BUILD_ERROR: -2,
+  KERNEL_PREFERRED_WORK_GROUP_SIZE_MULTIPLE: 0x11B3,
+};
+
+class WebCLDevice {
+  constructor(index) { this.index = index; }
+  getInfo(what) {
+    if (what === C.DEVICE_NAME) return wrap(() => native().deviceName(this.index));
+    if (what === C.DEVICE_TYPE) return C.DEVICE_TYPE_GPU;
+    throw new WebCLException("INVALID_VALUE", "device.getInfo: unsupported query " + what);
+  }
+}
+
+class WebCLPlatform {
+  getInfo(what) {
+    switch (what) {
+      case C.PLATFORM_NAME: return "mirt (AMD Instinct MI355X, HIP)";
+      case C.PLATFORM_VENDOR: return "2015-raytracing_amd";
+      case C.PLATFORM_VERSION: return "WebCL 1.0 subset over " + native().version();
+      case C.PLATFORM_PROFILE: return "FULL_PROFILE";
+      case C.PLATFORM_EXTENSIONS: return "mirt_render_pass";
+      default: throw new WebCLException("INVALID_VALUE", "platform.getInfo: unsupported query " + what);
+    }
+  }
+  getDevices(type) {
+    const n = native().deviceCount();
+    if (type !== C.DEVICE_TYPE_ALL && type !== C.DEVICE_TYPE_GPU) return [];
+    const out = [];
+    for (let i = 0; i < n; i++) out.push(new WebCLDevice(i));
+    return out;
+  }
+}
+
+class WebCLBuffer {
+  constructor(ctx, bytes, flags) {
+    this.ctx = ctx; this.byteLength = bytes;
+    this.h = wrap(() => native().bufCreate(ctx.h, bytes, flags));
+  }
+  release() { if (this.h) { wrap(() => native().bufRelease(this.h)); this.h = null; } }
+}
+
+class WebCLKernel {
+  constructor(program, name) {
+    this.ctx = program.ctx; this.name = name;
+    this.h = wrap(() => native().kernelGet(this.ctx.h, name));
+  }
+  setArg(index, value) {
+    if (value instanceof WebCLBuffer) {
+      if (!value.h) throw new WebCLException("INVALID_MEM_OBJECT", this.name + ".setArg(" + index + "): released buffer");
+      wrap(() => native().kernelSetArg(this.h, index, value.h));
+    } else if (ArrayBuffer.isView(value)) {
+      wrap(() => native().kernelSetArg(this.h, index, value));
+    } else throw new WebCLException("INVALID_ARG_VALUE", this.name + ".setArg(" + index + "): expected a WebCLBuffer or a typed array");
+  }
+  getWorkGroupInfo(device, what) {
+    if (what === C.KERNEL_PREFERRED_WORK_GROUP_SIZE_MULTIPLE) return wrap(() => native().kernelPreferredMultiple(this.h));
+    throw new WebCLException("INVALID_VALUE", "kernel.getWorkGroupInfo: unsupported query " + what);
+  }
+  release() { if (this.h) { wrap(() => native().kernelRelease(this.h)); this.h = null; } }
+}
+
+class WebCLProgram {
+  constructor(ctx, source) { this.ctx = ctx; this.source = String(source); this.status = null; this.log = ""; }
+  build() {
+    const r = wrap(() => native().programCheck(this.ctx.h, this.source));
+    this.log = r.missing ? "no built-in HIP kernel for: " + r.log : "";
+    this.status = r.missing ? C.BUILD_ERROR : C.BUILD_SUCCESS;
+    if (r.missing) throw new WebCLException("BUILD_PROGRAM_FAILURE", this.log);
+  }
+  getBuildInfo(device, what) {
+    if (what === C.PROGRAM_BUILD_STATUS) return this.status;
+    if (what === C.PROGRAM_BUILD_LOG) return this.log;
+    throw new WebCLException("INVALID_VALUE", "program.getBuildInfo: unsupported query " + what);
+  }
+  createKernel(name) { return new WebCLKernel(this, name); }
+  release() {}
+}
+
+class WebCLCommandQueue {
+  constructor(ctx) { this.ctx = ctx; }
+  enqueueWriteBuffer(buf, blocking, offset, nbytes, typedArray /*, events */) {
+    wrap(() => native().bufWrite(buf.h, offset, nbytes, typedArray));
+  }
+  enqueueReadBuffer(buf, blocking, offset, nbytes, typedArray /*, events */) {
+    wrap(() => native().bufRead(buf.h, offset, nbytes, typedArray));
+  }
+  enqueueNDRangeKernel(kernel, dim, globalOffset, globalWS, localWS) {
+    if (globalOffset) throw new WebCLException("INVALID_GLOBAL_OFFSET", "global offsets are not supported (the reference passes null)");
+    wrap(() => native().enqueue(this.ctx.h, kernel.h, dim, Array.from(globalWS), localWS ? Array.from(localWS) : null));
+  }
+  finish() { wrap(() => native().finish(this.ctx.h)); }
+  // ---- extension: one fused launch for the whole pass (mirt_render_pass) -------------------
+  renderPass(desc) {
+    const g = (s) => s && { prims: s.prims.h, normals: s.normals ? s.normals.h : undefined, matid: s.matid ? s.matid.h : undefined,
+                            cellOffsets: s.cellOffsets.h, bounds: s.bounds, nSlabs: s.nSlabs, meshMatId: s.meshMatId || 0 };
+    const d = Object.assign({}, desc, {
+      spheres: g(desc.spheres), triangles: g(desc.triangles), meshes: (desc.meshes || []).map(g),
+      material: desc.material.h, seeds: desc.seeds.h, acu: desc.acu.h,
+      pixel: desc.pixel ? desc.pixel.h : undefined, radiance: desc.radiance ? desc.radiance.h : undefined,
+    });
+    wrap(() => native().renderPass(this.ctx.h, d));
+  }
+  seedFill(buf, firstRay, count, seedBase) { wrap(() => native().seedFill(this.ctx.h, buf.h, firstRay, count, seedBase || 0)); }
+  zero(buf) { wrap(() => native().zero(this.ctx.h, buf.h)); }
+  timerStart() { wrap(() => native().timerStart(this.ctx.h)); }
+  timerStopMs() { return wrap(() => native().timerStopMs(this.ctx.h)); }
+  release() {}
+}
+
+class WebCLContext {
+  constructor(device) {
+    this.device = device || new WebCLDevice(0);
+    this.h = wrap(() => native().ctxCreate(this.device.index));
+  }
+  createCommandQueue() { return new WebCLCommandQueue(this); }
+  createProgram(source) { return new WebCLProgram(this, source); }
+  createBuffer(flags, bytes) { return new WebCLBuffer(this, bytes, flags); }
+  release() { if (this.h) { wrap(() => native().ctxDestroy(this.h)); this.h = null; } }
+}
+
+const webcl = Object.assign({
+  getPlatforms() { return [new WebCLPlatform()]; },
+  createContext(device) { return new WebCLContext(device); },
+}, C);
+
+// `window.WebCL` is only tested for existence by the reference (A10 code.js:468); `webcl` is the entry object.
+module.exports = { webcl, WebCL: C, WebCLException };

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmirt.so")
+LIB_PATH = os.environ.get("MIRT_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libmirt.so")  # override: A/B builds only
 
 MEM_READ_WRITE, MEM_WRITE_ONLY, MEM_READ_ONLY = 1, 2, 4
 MAX_LIGHTS, MAX_MESHES = 8, 16

@@ -53,12 +53,20 @@ CASES = [
     ("twoLights_32x24_r4", "twoLights.xml", 32, 24, 4, True),
     ("threeLights_32x24_r1", "threeLights.xml", 32, 24, 1, True),
     ("cornell_320x240_r16", "cornell.xml", 320, 240, 16, False),
+    # our own scenes (tests/scenes/page): inputs packed by the REFERENCE host code, outputs by the reference kernels
+    ("own_studio_48x36_r4", "@studio.xml", 48, 36, 4, True),
+    ("own_gems_48x36_r4", "@gems.xml", 48, 36, 4, True),
+    ("own_gems_64x48_r1", "@gems.xml", 64, 48, 1, True),
+    ("own_flat_32x24_r4", "@flat.xml", 32, 24, 4, True),
 ]
+OWN_PAGE = os.path.join(ROOT, "tests", "scenes", "page")
 
 
 def host_dump(scene, w, h, rpp):
-    out = subprocess.run(["node", os.path.join(HERE, "ref_host_dump.js"), REFROOT, scene, str(w), str(h), str(rpp)],
-                         check=True, capture_output=True, cwd="/tmp")
+    cmd = ["node", os.path.join(HERE, "ref_host_dump.js"), REFROOT, scene.lstrip("@"), str(w), str(h), str(rpp)]
+    if scene.startswith("@"):
+        cmd += ["1", OWN_PAGE]
+    out = subprocess.run(cmd, check=True, capture_output=True, cwd="/tmp")
     return out.stdout.decode()
 
 

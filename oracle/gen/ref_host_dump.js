@@ -7,21 +7,24 @@
 // stdout.  tests/golden/ fixtures are generated from this (gen_golden.py); our
 // own JS host (2015-raytracing_amd/host/) is tested against the same dump.
 //
-// usage: node ref_host_dump.js <REFROOT> <scene.xml> <width> <height> <rays_per_pixel> [n_slabs]
+// usage: node ref_host_dump.js <REFROOT> <scene.xml> <width> <height> <rays_per_pixel> [n_slabs] [pageDir]
+//   pageDir: where scenes/ and tri/ are read from (default: the reference's own Assign10 page); the host CODE
+//   always comes from REFROOT.
 "use strict";
 const fs = require("fs");
 const path = require("path");
 const vm = require("vm");
 const { JSDOM } = require("/usr/share/nodejs/jsdom");
 
-const [refroot, sceneName, W, H, RPP, NSLABS] = process.argv.slice(2);
+const [refroot, sceneName, W, H, RPP, NSLABS, PAGEDIR] = process.argv.slice(2);
 const adir = path.join(refroot, "Assign10-Path_Tracing");
+const datadir = PAGEDIR ? path.resolve(PAGEDIR) : adir;
 
 function XHR() {
   this.open = function (m, url) { this.url = url; };
   this.overrideMimeType = function () {};
   this.send = function () {
-    let txt = fs.readFileSync(path.join(adir, this.url), "utf8");
+    let txt = fs.readFileSync(path.join(datadir, this.url), "utf8");
     if (txt.charCodeAt(0) === 0xfeff) txt = txt.slice(1);
     this.responseText = txt;
     if (/\.xml$/.test(this.url)) {
@@ -48,7 +51,7 @@ for (const f of ["lib/gl-matrix.js", "lib/utilities.js", "tri/meshDataVersion1.j
   vm.runInContext(fs.readFileSync(path.join(adir, f), "utf8"), sandbox, { filename: f });
 }
 // the globals the page's controls would set (code.js:396-402, 444-446, 530-543)
-vm.runInContext(`width=${+W}; height=${+H}; rays_per_pixel=${+RPP}; n_slabs=${NSLABS ? +NSLABS : 1};`, sandbox);
+vm.runInContext(`width=${+W}; height=${+H}; rays_per_pixel=${+RPP}; n_slabs=${+NSLABS > 0 ? +NSLABS : 1};`, sandbox);
 
 const out = vm.runInContext(`(function(){
   var scene = loadScene("scenes/${sceneName}");

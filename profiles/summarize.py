@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""profiles/summarize.py <gpurun_out/prof_TAG> <profiles/DIR> -- condense one run_profile.sh output into
+kernel_stats.csv + pmc_summary.json (mean per dispatch, per kernel, per counter) and print the fused kernel's line."""
+import collections, csv, glob, json, os, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+shutil.copy(glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
+out = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    fs = glob.glob(os.path.join(src, d, "*/*_counter_collection.csv"))
+    if not fs:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        out.setdefault(r["Kernel_Name"].split("(")[0], {})["VGPR_Count"] = int(r["VGPR_Count"])
+    for k, v in agg.items():
+        out.setdefault(k, {}).update({c: {"mean_per_dispatch": sum(x) / len(x), "dispatches": len(x)} for c, x in v.items()})
+json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+f = out.get("pt::k_fusedPass", {})
+g = lambda c: f.get(c, {}).get("mean_per_dispatch", float("nan"))
+waves = g("SQ_WAVES")
+print(open(os.path.join(dst, "kernel_stats.csv")).read().split("\n")[1])
+print(f"k_fusedPass: VALU/wave {g('SQ_INSTS_VALU')/waves:.0f}  SALU/wave {g('SQ_INSTS_SALU')/waves:.0f}  VMEM_RD/wave {g('SQ_INSTS_VMEM_RD')/waves:.1f}  "
+      f"SMEM/wave {g('SQ_INSTS_SMEM')/waves:.1f}  lane-util {g('SQ_THREAD_CYCLES_VALU')/(g('SQ_INSTS_VALU')*64):.3f}  "
+      f"FETCH {g('FETCH_SIZE')*2*1024/1e9:.2f} GB(x2)  WRITE {g('WRITE_SIZE')*1024/1e9:.2f} GB  VGPR {f.get('VGPR_Count')}")

@@ -16,7 +16,12 @@ FULL_CASES = [
     "cornell_64x48_r1", "cornell_32x24_r4", "cornell_16x12_r9",
     "cornell_teapot3_64x48_r1", "cornell_teapot3_32x24_r4", "cornell_official_64x48_r1",
     "twoLights_32x24_r4", "threeLights_32x24_r1",
+    "own_studio_48x36_r4", "own_gems_48x36_r4", "own_gems_64x48_r1", "own_flat_32x24_r4",
 ]
+OWN_SCENES = {"own_studio_48x36_r4": ("studio.xml", 48, 36, 4), "own_gems_48x36_r4": ("gems.xml", 48, 36, 4),
+              "own_gems_64x48_r1": ("gems.xml", 64, 48, 1), "own_flat_32x24_r4": ("flat.xml", 32, 24, 4)}
+PAGE = os.path.join(ROOT, "tests", "scenes", "page")
+HOST = os.path.join(ROOT, "2015-raytracing_amd", "host")
 
 
 def pytest_configure(config):

@@ -1,0 +1,144 @@
+"""The JavaScript host (2015-raytracing_amd/host/): scene ingest on CPU, rendering through the N-API
+addon on the GPU.  Expected values come from the REFERENCE host code and kernels run in the build
+container on the same scene files (oracle/gen/gen_golden.py, cases own_*): the fixtures' scene_json is
+what the reference's loadScene/split*Data/Camera/Light produce for tests/scenes/page/."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import HOST, OWN_SCENES, PAGE, bits, load_fixture
+
+node = shutil.which("node")
+pytestmark = pytest.mark.skipif(node is None, reason="node is not installed")
+REF_PAGE = "/root/reference/Assign10-Path_Tracing"
+
+
+def run_node(*args, **kw):
+    r = subprocess.run([node] + list(args), capture_output=True, **kw)
+    assert r.returncode == 0, r.stderr.decode()
+    return r.stdout
+
+
+def same_packed(a, b, path=""):
+    if isinstance(a, dict):
+        assert set(a) == set(b), f"{path}: keys {set(a) ^ set(b)}"
+        for k in a:
+            same_packed(a[k], b[k], path + "/" + k)
+    elif isinstance(a, list) and a and isinstance(a[0], dict):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            same_packed(x, y, f"{path}[{i}]")
+    elif isinstance(a, list):
+        assert np.array_equal(np.asarray(a, np.float64), np.asarray(b, np.float64)), path
+    else:
+        assert a == b, path
+
+
+@pytest.mark.parametrize("name", sorted(OWN_SCENES))
+def test_pack_equals_reference_host(name):
+    """camera / light packs, grid-sorted geometry, cell offsets, AABBs: exactly the reference host's arrays."""
+    fx, _ = load_fixture(name)
+    scene, w, h, rpp = OWN_SCENES[name]
+    got = json.loads(run_node(os.path.join(HOST, "cli.js"), "pack", os.path.join(PAGE, "scenes", scene), str(w), str(h), str(rpp)))
+    same_packed(json.loads(bytes(fx["scene_json"]).decode()), got)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PAGE), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("scene", ["basic", "basic2", "cornell", "cornell_official", "cornell_teapot", "cornell_teapot2",
+                                   "cornell_teapot3", "threeLights", "triangles", "twoLights"])
+def test_reference_scenes_load_unchanged(scene):
+    """scenes/*.xml and tri/*.json of the reference, read where they lie: our host and the reference's own host code
+    (run in a vm sandbox) must emit identical buffers."""
+    dump = os.path.join(os.path.dirname(HOST), "..", "oracle", "gen", "ref_host_dump.js")
+    want = json.loads(run_node(dump, "/root/reference", scene + ".xml", "96", "64", "4", cwd="/tmp"))
+    got = json.loads(run_node(os.path.join(HOST, "cli.js"), "pack", f"{REF_PAGE}/scenes/{scene}.xml", "96", "64", "4"))
+    same_packed(want, got)
+
+
+def test_grid_builder_drops_primitives_on_the_max_face():
+    """min index clamped from below only, max index from above only (A10 code.js:948-953): a primitive lying entirely
+    on the max face gets lo = n > hi = n-1 and lands in no cell -- the reference's Cornell_box_model quirk."""
+    js = """
+      const s = require(process.argv[1]);
+      const b = new s.Bounds([0,0,0],[1,1,1]);
+      const boxes = [[[0.1,0.1,0.1],[0.2,0.2,0.2]], [[1,0,0],[1,1,1]], [[0.4,0.4,0.4],[0.6,0.6,0.6]], [[-1,-1,-1],[2,2,2]]];
+      const g = s.buildGrid(boxes.length, 2, b, (i) => boxes[i]);
+      console.log(JSON.stringify({off: Array.from(g.offsets), order: Array.from(g.order)}));
+    """
+    out = json.loads(run_node("-e", js, os.path.join(HOST, "scene.js")))
+    assert out["off"] == [0, 3, 5, 7, 9, 11, 13, 15, 17]
+    assert 1 not in out["order"]                      # the primitive on x = 1 is dropped
+    assert out["order"][:3] == [0, 2, 3]              # cell 0: input order, duplicates per cell
+    assert out["order"].count(2) == 8 and out["order"].count(3) == 8 and out["order"].count(0) == 1
+
+
+def test_xml_reader_handles_bom_comments_and_errors():
+    js = """
+      const s = require(process.argv[1]);
+      const d = s.parseXML("\\ufeff<?xml version='1.0'?><a><!-- c <b>9</b> --><b> 1.5 </b><c><b>2</b></c></a>");
+      const all = []; (function w(e){ for (const c of e.children) { if (c.name === 'b') all.push(Number(c.text)); w(c); } })(d);
+      let err = ''; try { s.parseXML('<a><b></a>'); } catch (e) { err = e.message; }
+      console.log(JSON.stringify({all: all, err: err}));
+    """
+    out = json.loads(run_node("-e", js, os.path.join(HOST, "scene.js")))
+    assert out["all"] == [1.5, 2] and "unbalanced" in out["err"]
+
+
+def test_webcl_surface_without_a_gpu():
+    """The WebCL-shaped object exists, carries the constants the reference host uses, and refuses to run without an MI355X."""
+    js = """
+      const { webcl } = require(process.argv[1]);
+      const need = ['DEVICE_NAME','DEVICE_TYPE','DEVICE_TYPE_ALL','DEVICE_TYPE_CPU','DEVICE_TYPE_GPU','KERNEL_PREFERRED_WORK_GROUP_SIZE_MULTIPLE',
+        'MEM_READ_ONLY','MEM_READ_WRITE','MEM_WRITE_ONLY','PLATFORM_NAME','PLATFORM_VENDOR','PLATFORM_VERSION','PLATFORM_PROFILE',
+        'PLATFORM_EXTENSIONS','PROGRAM_BUILD_STATUS','PROGRAM_BUILD_LOG'];
+      const missing = need.filter((k) => webcl[k] === undefined);
+      const p = webcl.getPlatforms();
+      const nd = p[0].getDevices(webcl.DEVICE_TYPE_ALL).length;
+      let err = '';
+      if (nd === 0) { try { webcl.createContext(); } catch (e) { err = e.name + ': ' + e.message; } }
+      console.log(JSON.stringify({missing: missing, platforms: p.length, name: p[0].getInfo(webcl.PLATFORM_NAME), nd: nd, err: err}));
+    """
+    out = json.loads(run_node("-e", js, os.path.join(HOST, "webcl.js")))
+    assert out["missing"] == [] and out["platforms"] == 1 and "MI355X" in out["name"]
+    if out["nd"] == 0:
+        assert "DEVICE_NOT_FOUND" in out["err"] and "no CPU fallback" in out["err"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fused", "granular"])
+@pytest.mark.parametrize("name", sorted(OWN_SCENES))
+def test_node_render_matches_compiled_reference(tmp_path, name, mode):
+    """scene.xml -> JS host -> N-API addon -> C ABI -> HIP kernels -> frame, against the compiled reference's frame."""
+    fx, sc = load_fixture(name)
+    scene, w, h, rpp = OWN_SCENES[name]
+    out = str(tmp_path / "frame.rgba")
+    args = [os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", scene), str(w), str(h), str(rpp), "1", out]
+    if mode == "granular":
+        args.append("--granular")
+    run_node(*args)
+    pix = np.fromfile(out, np.uint8).reshape(-1, 4)
+    rad = np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)
+    assert np.array_equal(pix, fx["pixel"])
+    assert np.array_equal(bits(rad), bits(fx["radiance"]))
+
+
+@pytest.mark.gpu
+def test_node_progressive_passes_and_explicit_seeds(tmp_path):
+    """three passes with host-supplied seeds (the reference uploads a seed array, A10 code.js:1140-1154) == oracle."""
+    import a10_pass as A
+    fx, sc = load_fixture("own_studio_48x36_r4")
+    seeds = A.make_seeds(sc.total_rays, seed_base=1234)
+    sfile = str(tmp_path / "seeds.i32")
+    seeds.tofile(sfile)
+    st = A.PassState(sc, seeds)
+    orc = A.load_oracle()
+    for p in range(3):
+        A.run_pass(orc, sc, st, init_acu=(p == 0))
+    out = str(tmp_path / "frame.rgba")
+    run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "studio.xml"), "48", "36", "4", "3", out, "--seeds", sfile)
+    assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), st.pixel)
+    assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(A.radiance_sums(st.acu, 4)))
