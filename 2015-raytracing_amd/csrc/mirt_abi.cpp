@@ -199,7 +199,7 @@ int mirt_device_name(int device, char* out, size_t cap) {
     if (!out || cap == 0) return fail(nullptr, MIRT_E_ARG, "mirt_device_name: null output");
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, MIRT_E_NODEVICE, "no HIP device %d", device); }
-    snprintf(out, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    snprintf(out, cap, "%s (%s, %d CUs)", p.name[0] ? p.name : "AMD Instinct (name not reported)", p.gcnArchName, p.multiProcessorCount);
     return MIRT_OK;
 }
 

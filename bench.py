@@ -44,9 +44,9 @@ def cpu_baseline(packed_json, log):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import a10_pass as A
     d = json.loads(packed_json)
-    w, h, rpp = 240, 135, 256
+    w, h, rpp = 480, 270, 256
     cam = list(d["cam"])
-    cam[14], cam[15] = float(w), float(h)   # same 16:9 frustum, 1/8 of the pixels per side
+    cam[14], cam[15] = float(w), float(h)   # same 16:9 frustum, 1/4 of the pixels per side
     d.update(cam=cam, width=w, height=h, rays_per_pixel=rpp)
     sc = A.Scene(d)
     k = A.load_oracle()
@@ -92,7 +92,7 @@ def main():
             print(msg, file=sys.stderr, flush=True)
 
     graft.load_package()
-    from raytracing_amd.pyhost import mirt, render, scene
+    from raytracing_amd.pyhost import mirt, render, scene, tiling
 
     name = f"scene_cornell_{args.width}x{args.height}_r{args.rpp}.json"
     path = os.path.join(ROOT, "tests", "golden", name)
@@ -104,12 +104,8 @@ def main():
         sc = scene.PackedScene(packed).resized(args.width, args.height, args.rpp)
 
     # contiguous row tiles
-    H = sc.height
-    base, extra = divmod(H, world)
-    rows = [base + (1 if r < extra else 0) for r in range(world)]
-    row0 = sum(rows[:rank])
-    nrows = rows[rank]
-    max_rows = max(rows)
+    row0, nrows = tiling.row_tiles(sc.height, world)[rank]
+    max_rows = tiling.padded_rows(sc.height, world)
 
     ctx = mirt.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -129,7 +125,7 @@ def main():
         fr.passes = 1
         fr.execute_render(bounces=args.bounces)
         if world > 1:
-            dist.all_gather_into_tensor(frame, tile)
+            tiling.gather_tiles(tile, frame)
 
     def fence():
         torch.cuda.synchronize()

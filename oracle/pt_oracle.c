@@ -364,15 +364,21 @@ void oracle_a10_initTrace(int* seeds, void* rays_, void* pois_, const float* bou
     box_t bound = ld_box(bound8);
     pto_ray* rays = (pto_ray*)rays_;
     pto_poi* pois = (pto_poi*)pois_;
-    for (size_t row = 0; row < gy; ++row) {
-        for (size_t col = 0; col < gx; ++col) {
-            if (col >= cam.cols || row >= cam.rows) continue;
-            size_t base = ((size_t)cam.cols * row + col) * rpp;
-            v3 fp = focal_point(&cam, (float)(uint32_t)col, (float)(uint32_t)row, focal_length);
-            if (rpp > 1) {
-                FL(3);
-                uint32_t side = cln_f2u(cln_sqrt((float)rpp));
-                float delta = 1.0f / (float)side;
+    if (rpp > 1) {
+        /* no RNG draws on this branch: pixels are independent, rows go to threads */
+        const uint32_t side = cln_f2u(cln_sqrt((float)rpp));
+        const float delta = 1.0f / (float)side;
+        const long rows = (long)(gy < cam.rows ? gy : cam.rows);
+        const size_t cols = gx < cam.cols ? gx : cam.cols;
+        FL(2);
+#if defined(_OPENMP) && !defined(PTO_COUNT_FLOPS)
+#pragma omp parallel for schedule(static, 4)
+#endif
+        for (long row = 0; row < rows; ++row) {
+            for (size_t col = 0; col < cols; ++col) {
+                size_t base = ((size_t)cam.cols * (size_t)row + col) * rpp;
+                v3 fp = focal_point(&cam, (float)(uint32_t)col, (float)(uint32_t)row, focal_length);
+                FL(1);
                 float cy = delta / 2.0f;
                 for (uint32_t i = 0; i < side; ++i) {
                     FL(1);
@@ -385,15 +391,25 @@ void oracle_a10_initTrace(int* seeds, void* rays_, void* pois_, const float* bou
                     FL(1);
                     cy += delta;
                 }
-            } else {
-                float cy = get_rand(&seeds[col]);
-                float cx = get_rand(&seeds[col]);
-                clip_and_store(&rays[base], thin_lens_ray(&cam, fp, lens_rad, cx, cy), &bound);
+                for (unsigned i = 0; i < rpp; ++i) {
+                    pois[base + i].matId = -1;
+                    pois[base + i].atte[0] = 1.0f; pois[base + i].atte[1] = 1.0f; pois[base + i].atte[2] = 1.0f;
+                }
             }
-            for (unsigned i = 0; i < rpp; ++i) {
-                pois[base + i].matId = -1;
-                pois[base + i].atte[0] = 1.0f; pois[base + i].atte[1] = 1.0f; pois[base + i].atte[2] = 1.0f;
-            }
+        }
+        return;
+    }
+    /* rpp == 1: strictly sequential, row-major -- the order defines which draws a pixel gets */
+    for (size_t row = 0; row < gy; ++row) {
+        for (size_t col = 0; col < gx; ++col) {
+            if (col >= cam.cols || row >= cam.rows) continue;
+            size_t base = (size_t)cam.cols * row + col;
+            v3 fp = focal_point(&cam, (float)(uint32_t)col, (float)(uint32_t)row, focal_length);
+            float cy = get_rand(&seeds[col]);
+            float cx = get_rand(&seeds[col]);
+            clip_and_store(&rays[base], thin_lens_ray(&cam, fp, lens_rad, cx, cy), &bound);
+            pois[base].matId = -1;
+            pois[base].atte[0] = 1.0f; pois[base].atte[1] = 1.0f; pois[base].atte[2] = 1.0f;
         }
     }
 }
