@@ -142,3 +142,19 @@ def test_node_progressive_passes_and_explicit_seeds(tmp_path):
     run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "studio.xml"), "48", "36", "4", "3", out, "--seeds", sfile)
     assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), st.pixel)
     assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(A.radiance_sums(st.acu, 4)))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PAGE), reason="reference tree not present (GPU box)")
+def test_unmodified_reference_page_script_boots_on_our_webcl():
+    """host/harness.js loads the reference's code.js + lib/ + tri/ UNMODIFIED with our `webcl`; without a GPU it must get as
+    far as device discovery and scene loading (updateScene -> loadScene through our XHR/DOM stubs) and stop at 'no devices'."""
+    js = """
+      const h = require(process.argv[1]);
+      const r = h.run(process.argv[2], 'cornell_teapot3.xml', 64, 48, 2, 1);
+      const sb = h.makeSandbox(process.argv[2], {width: 64, height: 48});
+      console.log(JSON.stringify({devices: r.devices, hasFrame: !!r.frame, fns: ['preRender','executeRender','loadScene','splitMeshData'].map((f) => typeof sb[f])}));
+    """
+    out = json.loads(run_node("-e", js, os.path.join(HOST, "harness.js"), REF_PAGE))
+    assert out["fns"] == ["function"] * 4
+    if out["devices"] == 0:
+        assert out["hasFrame"] is False
