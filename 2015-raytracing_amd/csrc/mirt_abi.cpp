@@ -592,6 +592,19 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     memcpy(o->bound, g->bounds, sizeof o->bound);
     o->n = g->n_slabs;
     o->mesh_matid = g->mesh_matid;
+    o->exit_is_far_face = 0;
+    if (g->n_slabs == 1) {
+        // A10 code.cl:699-707 with n = 1: x_next = pmin + (0 + (d>=0)) * ((pmax-pmin)/1).  When that reproduces pmax / pmin
+        // bit for bit, t_next is the very quotient interAABB already formed for the far slab plane.
+        bool exact = true;
+        for (int k = 0; k < 3; ++k) {
+            volatile float lo = g->bounds[k], hi = g->bounds[4 + k];
+            volatile float delta = (hi - lo) / 1.0f;
+            volatile float up = lo + 1.0f * delta, dn = lo + 0.0f * delta;
+            exact = exact && (up == hi) && (dn == lo) && (up == up);
+        }
+        o->exit_is_far_face = exact ? 1u : 0u;
+    }
     return MIRT_OK;
 }
 

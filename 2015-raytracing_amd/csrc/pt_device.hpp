@@ -120,14 +120,15 @@ PT_DEV Ray thin_lens_ray(const Cam& c, f3 fp, float lens_rad, float cx, float cy
 }
 
 // ---- ray / box: A10 code.cl:335-389 ---------------------------------------------------
-struct BoxHit { float tmin, tmax; bool v; };
+struct BoxHit { float tmin, tmax; bool v; float tfx, tfy, tfz; };   // tf*: per-axis exit parameter (the slab's far t)
 
-PT_DEV bool slab1(float lo, float hi, float o, float d, BoxHit& h) {
+PT_DEV bool slab1(float lo, float hi, float o, float d, BoxHit& h, float& tfar) {
     float t0 = (lo - o) / d;
     float t1 = (hi - o) / d;
     const bool neg = d < 0;
     float tn = neg ? t1 : t0;
     float tf = neg ? t0 : t1;
+    tfar = tf;
     h.tmin = cl_max(tn, h.tmin);
     h.tmax = cl_min(tf, h.tmax);
     return !(h.tmin > h.tmax);
@@ -139,9 +140,9 @@ PT_DEV BoxHit inter_aabb(const Ray& r, const Box& b) {
     BoxHit h;
     h.tmin = 0.0f;
     h.tmax = PT_INF;
-    const bool okx = slab1(b.lo.x, b.hi.x, r.o.x, r.d.x, h);
-    const bool oky = slab1(b.lo.y, b.hi.y, r.o.y, r.d.y, h);
-    const bool okz = slab1(b.lo.z, b.hi.z, r.o.z, r.d.z, h);
+    const bool okx = slab1(b.lo.x, b.hi.x, r.o.x, r.d.x, h, h.tfx);
+    const bool oky = slab1(b.lo.y, b.hi.y, r.o.y, r.d.y, h, h.tfy);
+    const bool okz = slab1(b.lo.z, b.hi.z, r.o.z, r.d.z, h, h.tfz);
     h.v = okx && oky && okz;
     return h;
 }

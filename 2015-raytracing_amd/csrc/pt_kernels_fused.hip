@@ -26,6 +26,10 @@
 #include "pt_device.hpp"
 #include "pt_launch.hpp"
 
+#ifndef PT_OPT_PREFETCH
+#define PT_OPT_PREFETCH 0
+#endif
+
 namespace pt {
 
 // prepared triangle: 3 x float4 = {p0.xyz, n.x} {e1.xyz, n.y} {e2.xyz, n.z}
@@ -107,19 +111,49 @@ PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         // axis_setup with n == 1: slab = 0, the cell exit is the far face as the reference computes
         // it, lo + (0 + (d>=0)) * ((hi-lo)/1)   (A10 code.cl:699-707)
         float tn[3];
-        const float lo[3] = {S.bound[0], S.bound[1], S.bound[2]}, hi[3] = {S.bound[4], S.bound[5], S.bound[6]};
-        const float oo[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
+        if (S.exit_is_far_face) {  // host-verified: the cell's exit planes ARE the box's far planes (see mirt_abi.cpp)
+            tn[0] = bh.tfx; tn[1] = bh.tfy; tn[2] = bh.tfz;
+        } else {
+            const float lo[3] = {S.bound[0], S.bound[1], S.bound[2]}, hi[3] = {S.bound[4], S.bound[5], S.bound[6]};
+            const float oo[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float delta = (hi[k] - lo[k]) / 1.0f;
-            float xnext = lo[k] + (float)((dd[k] >= 0) ? 1 : 0) * delta;
-            tn[k] = (xnext - oo[k]) / dd[k];
+            for (int k = 0; k < 3; ++k) {
+                float delta = (hi[k] - lo[k]) / 1.0f;
+                float xnext = lo[k] + (float)((dd[k] >= 0) ? 1 : 0) * delta;
+                tn[k] = (xnext - oo[k]) / dd[k];
+            }
         }
         const float cmin = bh.tmin;
         const float cmax = cl_min(cl_min(tn[0], tn[1]), tn[2]);
         const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
         const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
         bool done = false;
+#if PT_OPT_PREFETCH
+        // software pipeline: the next primitive's scalar loads are issued before the current test's ~60 VALU ops
+        float4 A = make_float4(0, 0, 0, 0), B = A, C = A;
+        if (begin < end) {
+            if (KIND == SPHERES) A = prims[begin];
+            else { A = prims[3u * begin]; B = prims[3u * begin + 1]; C = prims[3u * begin + 2]; }
+        }
+        for (uint32_t i = begin; i < end; ++i) {
+            float4 nA = A, nB = B, nC = C;
+            if (i + 1 < end) {
+                if (KIND == SPHERES) nA = prims[i + 1];
+                else { nA = prims[3u * (i + 1)]; nB = prims[3u * (i + 1) + 1]; nC = prims[3u * (i + 1) + 2]; }
+            }
+            float ti, b = 0.0f, gm = 0.0f;
+            bool hit;
+            if (KIND == SPHERES) hit = sph_test(ray.o, ray.d, sr, cmin, cmax, A, ti);
+            else hit = tri_test(ray.o, ray.d, cmin, cmax, A, B, C, ti, b, gm);
+            const bool better = !done && hit && ti < ch.t;
+            if (better) { ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm; }
+            if (ANY) {
+                done = done || better;
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            }
+            A = nA; B = nB; C = nC;
+        }
+#else
         for (uint32_t i = begin; i < end; ++i) {
             float ti, b = 0.0f, gm = 0.0f;
             bool hit;
@@ -135,6 +169,7 @@ PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
                 if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every lane of the wave is blocked
             }
         }
+#endif
         return ch;
     }
 
@@ -242,8 +277,11 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc)
     }
 }
 
+#ifndef PT_OPT_PREFETCH
+#define PT_OPT_PREFETCH 0
+#endif
 #ifndef PT_FUSED_WAVES
-#define PT_FUSED_WAVES 4   // waves per SIMD the register allocator must leave room for
+#define PT_FUSED_WAVES 6   // waves per SIMD the register allocator must leave room for (A/B: 4 -> 213 ms, 5 -> 205, 6 -> 200, 8 -> 243 with spills)
 #endif
 __global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedArgs A) {
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;

@@ -206,21 +206,41 @@ __global__ void __launch_bounds__(256) k_sceneRender(float4* acu, PoiAoS* pois, 
 }
 
 // code.cl:1366-1386; `radiance` (optional) receives the un-scaled sequential fp32 sums.
-__global__ void __launch_bounds__(256) k_copyToPixel(uchar4* pixel, const float4* acu, float m, uint32_t pixels, uint32_t rpp,
-                                                      uint32_t gsz, float4* radiance) {
-    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= gsz || id >= pixels) return;
-    const float4* a = acu + (size_t)id * rpp;
+// One wave per 64 pixels.  The reference's work-item walks its own run of rpp float4s (4 KB apart
+// from its neighbour's at rpp = 256: every lane on a different line, 4x over-fetch measured); here
+// the wave stages 64 pixels x 16 samples through LDS with coalesced 256-B runs, then each lane adds
+// its pixel's samples in the reference's order (the fp32 sum is order-dependent).
+constexpr int kResS = 16;   // samples per staged chunk
+__global__ void __launch_bounds__(64) k_copyToPixel(uchar4* pixel, const float4* acu, float m, uint32_t pixels, uint32_t rpp,
+                                                     uint32_t gsz, float4* radiance) {
+    __shared__ float4 tile[64][kResS + 1];   // +1: lanes 16 apart land on different banks for ds_read_b128
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pix0 = blockIdx.x * 64u;
+    const uint32_t id = pix0 + lane;
+    const uint32_t lim = pixels < gsz ? pixels : gsz;
     float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (uint32_t i = 0; i < rpp; ++i) {
-        float4 v = a[i];
-        c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;
+    for (uint32_t s0 = 0; s0 < rpp; s0 += kResS) {
+        const uint32_t ns = (rpp - s0) < (uint32_t)kResS ? (rpp - s0) : (uint32_t)kResS;
+#pragma unroll
+        for (int it = 0; it < kResS; ++it) {
+            const uint32_t idx = (uint32_t)it * 64u + lane;
+            const uint32_t px = idx / kResS, s = idx % kResS;
+            if (s < ns && pix0 + px < lim) tile[px][s] = acu[(size_t)(pix0 + px) * rpp + s0 + s];
+        }
+        __syncthreads();
+        if (id < lim)
+            for (uint32_t s = 0; s < ns; ++s) {
+                const float4 v = tile[lane][s];
+                c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;
+            }
+        __syncthreads();
     }
+    if (id >= lim) return;
     if (radiance) radiance[id] = c;
-    float s = 255.0f * m;
-    c.x = cl_clamp((c.x * s) * 1.8f, 0.0f, 255.0f);
-    c.y = cl_clamp((c.y * s) * 1.8f, 0.0f, 255.0f);
-    c.z = cl_clamp((c.z * s) * 1.8f, 0.0f, 255.0f);
+    float sc = 255.0f * m;
+    c.x = cl_clamp((c.x * sc) * 1.8f, 0.0f, 255.0f);
+    c.y = cl_clamp((c.y * sc) * 1.8f, 0.0f, 255.0f);
+    c.z = cl_clamp((c.z * sc) * 1.8f, 0.0f, 255.0f);
     if (pixel) pixel[id] = make_uchar4((unsigned char)f2u(c.x), (unsigned char)f2u(c.y), (unsigned char)f2u(c.z), 255);
 }
 
@@ -334,7 +354,7 @@ void launch_sceneRender(hipStream_t s, void* acu, void* pois, const void* shadow
 }
 void launch_copyToPixel(hipStream_t s, void* pixel, const void* acu, float m, uint32_t pixels, uint32_t rpp, uint32_t gsz, void* radiance) {
     if (!gsz) return;
-    hipLaunchKernelGGL(k_copyToPixel, grid1(gsz), dim3(256), 0, s, (uchar4*)pixel, (const float4*)acu, m, pixels, rpp, gsz, (float4*)radiance);
+    hipLaunchKernelGGL(k_copyToPixel, grid1(gsz, 64), dim3(64), 0, s, (uchar4*)pixel, (const float4*)acu, m, pixels, rpp, gsz, (float4*)radiance);
 }
 void launch_numerics(hipStream_t s, int op, const void* a, const void* b, void* out, uint64_t n) {
     if (!n) return;

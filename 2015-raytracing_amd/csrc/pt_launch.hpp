@@ -41,7 +41,8 @@ struct GridArgs {            // one cell-sorted primitive set, device pointers
     uint32_t n;              // cells per axis
     uint32_t mesh_matid;
     uint32_t kind;           // KIND_SPHERES | KIND_TRIANGLES
-    uint32_t _pad;
+    uint32_t exit_is_far_face; // n == 1 only: lo + 1*((hi-lo)/1) == hi and lo + 0*((hi-lo)/1) == lo hold bitwise on all three
+                             // axes (checked on the host), so the single cell's exit t equals the AABB slab's far t
 };
 struct LightArgs {           // the three float16 packings of one light (A10 code.js:323-352)
     float shadow[16];        // pos, T, B, radius

@@ -14,5 +14,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "${OUT}/pmc_fet
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "${OUT}/pmc_write" -- "${BENCH[@]}" > "${OUT}/pmc_write.log" 2>&1 || exit 13
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "${OUT}/pmc_sq" -- "${BENCH[@]}" > "${OUT}/pmc_sq.log" 2>&1 || exit 14
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d "${OUT}/pmc_sq2" -- "${BENCH[@]}" > "${OUT}/pmc_sq2.log" 2>&1 || exit 15
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_BRANCH SQ_INSTS_VALU --output-format csv -d "${OUT}/pmc_mix" -- "${BENCH[@]}" > "${OUT}/pmc_mix.log" 2>&1 || exit 16
+rocprofv3 --kernel-trace --pmc SQ_IFETCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_LEVEL_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "${OUT}/pmc_sq3" -- "${BENCH[@]}" > "${OUT}/pmc_sq3.log" 2>&1 || exit 17
+rocprofv3 --kernel-trace --pmc SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_ICACHE_REQ SQC_DCACHE_REQ --output-format csv -d "${OUT}/pmc_sqc" -- "${BENCH[@]}" > "${OUT}/pmc_sqc.log" 2>&1 || exit 18
 find "${OUT}" -name "*.csv" | head -40 > "${OUT}/files.txt"
 echo done

@@ -7,7 +7,7 @@ src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 shutil.copy(glob.glob(os.path.join(src, "trace/*/*_kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
 out = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mix", "pmc_sq3", "pmc_sqc"):
     fs = glob.glob(os.path.join(src, d, "*/*_counter_collection.csv"))
     if not fs:
         continue
