@@ -195,6 +195,15 @@ napi_value ProgramCheck(napi_env env, napi_callback_info info) {
     return o;
 }
 
+napi_value ProgramDialect(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    size_t len = 0;
+    if (napi_get_value_string_utf8(env, argv[0], nullptr, 0, &len) != napi_ok) return throw_type(env, "programDialect(source)");
+    std::string src(len + 1, '\0');
+    napi_get_value_string_utf8(env, argv[0], &src[0], len + 1, &len);
+    return mk_num(env, mirt_program_dialect(src.c_str()));
+}
+
 napi_value KernelGet(napi_env env, napi_callback_info info) {
     ARGS(2);
     void* c; char name[128]; size_t len;
@@ -369,7 +378,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"deviceCount", DeviceCount}, {"deviceName", DeviceName}, {"version", Version},
         {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"finish", Finish},
         {"bufCreate", BufCreate}, {"bufRelease", BufRelease}, {"bufSize", BufSize}, {"bufWrite", BufWrite}, {"bufRead", BufRead},
-        {"programCheck", ProgramCheck}, {"kernelGet", KernelGet}, {"kernelRelease", KernelRelease}, {"kernelNumArgs", KernelNumArgs},
+        {"programCheck", ProgramCheck}, {"programDialect", ProgramDialect}, {"kernelGet", KernelGet}, {"kernelRelease", KernelRelease}, {"kernelNumArgs", KernelNumArgs},
         {"kernelPreferredMultiple", KernelPreferredMultiple}, {"kernelSetArg", KernelSetArg}, {"enqueue", Enqueue},
         {"renderPass", RenderPass}, {"seedFill", SeedFill}, {"zero", Zero}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
     };

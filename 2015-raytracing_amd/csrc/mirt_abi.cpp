@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -68,7 +69,8 @@ struct mirt_buf {
 enum ArgType { A_BUF, A_U32, A_F32, A_F16, A_AABB };
 enum KernelId {
     K_sizeofRay, K_sizeofPoi, K_initAcu, K_initTrace, K_sphereTrace, K_triangleTrace, K_meshTrace, K_lightRender,
-    K_initShadowTrace, K_sphereShadowTrace, K_triangleShadowTrace, K_sceneRender, K_bouncePaths, K_copyToPixel, K_COUNT
+    K_initShadowTrace, K_sphereShadowTrace, K_triangleShadowTrace, K_sceneRender, K_bouncePaths, K_copyToPixel,
+    K_a01_raytrace, K_a04_sizeofRay, K_a04_initTrace, K_a04_meshTrace, K_a07_sizeofRay, K_a07_initTrace, K_a07_meshTrace, K_COUNT
 };
 
 struct KernelSpec { const char* name; KernelId id; std::vector<ArgType> args; };
@@ -90,6 +92,15 @@ static const std::vector<KernelSpec>& kernel_table() {
         {"sceneRender", K_sceneRender, {A_BUF, A_BUF, A_BUF, A_BUF, A_F16, A_U32}},
         {"bouncePaths", K_bouncePaths, {A_BUF, A_BUF, A_BUF, A_U32}},
         {"copyToPixel", K_copyToPixel, {A_BUF, A_BUF, A_F32, A_U32, A_U32}},
+        // earlier assignments, selected with a dialect prefix (their kernel names collide with A10's):
+        // A01 code.cl:116; A04 code.cl:200-315; A07 code.cl:307-626
+        {"A01:raytrace", K_a01_raytrace, {A_BUF, A_F16}},
+        {"A04:sizeofRay", K_a04_sizeofRay, {A_BUF}},
+        {"A04:initTrace", K_a04_initTrace, {A_BUF, A_F16, A_BUF}},
+        {"A04:meshTrace", K_a04_meshTrace, {A_BUF, A_F16, A_BUF, A_U32, A_BUF, A_BUF, A_BUF, A_BUF}},
+        {"A07:sizeofRay", K_a07_sizeofRay, {A_BUF}},
+        {"A07:initTrace", K_a07_initTrace, {A_BUF, A_F16, A_BUF, A_AABB}},
+        {"A07:meshTrace", K_a07_meshTrace, {A_BUF, A_F16, A_BUF, A_U32, A_BUF, A_BUF, A_BUF, A_BUF, A_AABB, A_U32, A_BUF}},
     };
     return t;
 }
@@ -172,6 +183,17 @@ int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const
     if (rc) return rc;
     if (normals && (rc = need(ctx, what, normals, count * prim_stride))) return rc;
     if (matid && (rc = need(ctx, what, matid, count * 4))) return rc;
+    return MIRT_OK;
+}
+
+// (re)builds the prepared-triangle copy of a position buffer when its contents changed
+int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
+    const size_t bytes = (size_t)count * 48;
+    if (pb->prep_version == pb->version && pb->prep_bytes >= bytes && (pb->prep || !bytes)) return MIRT_OK;
+    if (pb->prep) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pb->prep)); pb->prep = nullptr; pb->prep_bytes = 0; }
+    if (bytes) { HIPCHK(ctx, hipMalloc(&pb->prep, bytes)); pb->prep_bytes = bytes; }
+    pt::launch_prepTriangles(ctx->stream, pb->ptr, pb->prep, count);
+    pb->prep_version = pb->version;
     return MIRT_OK;
 }
 
@@ -335,40 +357,62 @@ int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* host, int b
     return MIRT_OK;
 }
 
+// OpenCL C text with comments blanked out, and the names of its `__kernel void NAME(` definitions
+static void scan_source(const char* source, std::string* code, std::vector<std::string>* kernels) {
+    const char* p = source;
+    while (*p) {
+        if (p[0] == '/' && p[1] == '*') { p += 2; while (*p && !(p[0] == '*' && p[1] == '/')) ++p; if (*p) p += 2; code->push_back(' '); continue; }
+        if (p[0] == '/' && p[1] == '/') { while (*p && *p != '\n') ++p; continue; }
+        code->push_back(*p++);
+    }
+    size_t pos = 0;
+    while ((pos = code->find("__kernel", pos)) != std::string::npos) {
+        size_t q = pos + 8;
+        auto ws = [&](size_t i) { while (i < code->size() && strchr(" \t\r\n", (*code)[i])) ++i; return i; };
+        q = ws(q);
+        if (code->compare(q, 4, "void") == 0) {
+            q = ws(q + 4);
+            size_t e = q;
+            while (e < code->size() && (isalnum((unsigned char)(*code)[e]) || (*code)[e] == '_')) ++e;
+            if (e > q) kernels->push_back(code->substr(q, e - q));
+        }
+        pos += 8;
+    }
+}
+
+int mirt_program_dialect(const char* source) {
+    if (!source) return 0;
+    std::string code;
+    std::vector<std::string> ks;
+    scan_source(source, &code, &ks);
+    auto has = [&](const char* k) { for (auto& n : ks) if (n == k) return true; return false; };
+    auto text = [&](const char* t) { return code.find(t) != std::string::npos; };
+    if (has("bouncePaths") && has("sceneRender")) return 10;
+    if (has("sceneRender") || has("initShadowTrace")) return 0;      // A08 / A09: earlier drafts of the A10 set, not built
+    if (has("meshTrace")) {
+        if (text("z_stride")) return 7;                              // 3-D grid (A07 code.cl:545)
+        if (!text("n_slabs") && !text("AABB bound")) return 4;       // brute force, no pre-clip (A04)
+        return 0;                                                    // A05 / A06: not built
+    }
+    if (ks.size() == 1 && ks[0] == "raytrace" && !text("__global float4")) return 1;   // A02's raytrace takes atom arrays
+    return 0;
+}
+
 int mirt_program_check(mirt_ctx* ctx, const char* source, char* missing, size_t cap) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_program_check: unknown context");
     if (!source) return fail(ctx, MIRT_E_ARG, "mirt_program_check: null source");
-    std::string miss;
+    std::string code, miss;
+    std::vector<std::string> ks;
+    scan_source(source, &code, &ks);
+    const int dialect = mirt_program_dialect(source);
+    const std::string prefix = dialect == 7 ? "A07:" : dialect == 4 ? "A04:" : dialect == 1 ? "A01:" : "";
     int n_missing = 0;
-    const char* p = source;
-    bool in_block_comment = false;
-    // scan for `__kernel void NAME (` outside comments
-    while (*p) {
-        if (in_block_comment) {
-            if (p[0] == '*' && p[1] == '/') { in_block_comment = false; p += 2; } else ++p;
-            continue;
-        }
-        if (p[0] == '/' && p[1] == '*') { in_block_comment = true; p += 2; continue; }
-        if (p[0] == '/' && p[1] == '/') { while (*p && *p != '\n') ++p; continue; }
-        if (strncmp(p, "__kernel", 8) == 0) {
-            const char* q = p + 8;
-            while (*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r') ++q;
-            if (strncmp(q, "void", 4) == 0) {
-                q += 4;
-                while (*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r') ++q;
-                const char* b = q;
-                while ((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || (*q >= '0' && *q <= '9') || *q == '_') ++q;
-                std::string name(b, q);
-                bool found = false;
-                for (const auto& s : kernel_table()) if (name == s.name) found = true;
-                if (!found && !name.empty()) { if (n_missing++) miss += ","; miss += name; }
-            }
-            p = q;
-            continue;
-        }
-        ++p;
+    for (const auto& name : ks) {
+        bool found = false;
+        for (const auto& k : kernel_table()) if (prefix + name == k.name) found = true;
+        if (!found) { if (n_missing++) miss += ","; miss += name; }
     }
-    if (missing && cap) { snprintf(missing, cap, "%s", miss.c_str()); }
+    if (missing && cap) snprintf(missing, cap, "%s", miss.c_str());
     return n_missing;
 }
 
@@ -554,6 +598,52 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
             pt::launch_copyToPixel(st, BUF(0)->ptr, BUF(1)->ptr, F(2), U(3), U(4), g0, nullptr);
             break;
         }
+        case K_a04_sizeofRay:
+        case K_a07_sizeofRay:
+            if ((rc = need(ctx, S.name, BUF(0), 4))) return rc;
+            pt::launch_sizeof(st, true, (uint32_t*)BUF(0)->ptr);
+            break;
+        case K_a01_raytrace: {
+            if (dim != 2) return fail(ctx, MIRT_E_ARG, "raytrace is a 2-D NDRange (A01 code.js:241)");
+            const uint32_t g1 = (uint32_t)global[1];
+            const uint32_t rows = f2u_host(V(1)[14]), cols = f2u_host(V(1)[15]);   // A01 packs rows, cols (code.js:50)
+            const uint32_t wc = std::min(g0, cols), wr = std::min(g1, rows);
+            if (wc && wr) {
+                if ((rc = need(ctx, "raytrace pixels", BUF(0), ((uint64_t)cols * (wr - 1) + wc) * 4))) return rc;
+                pt::launch_a01_raytrace(st, BUF(0)->ptr, V(1), g0, g1);
+            }
+            break;
+        }
+        case K_a04_initTrace:
+        case K_a07_initTrace:
+        case K_a04_meshTrace:
+        case K_a07_meshTrace: {
+            if (dim != 2) return fail(ctx, MIRT_E_ARG, "%s is a 2-D NDRange", S.name);
+            const uint32_t g1 = (uint32_t)global[1];
+            const uint32_t cols = f2u_host(V(1)[14]), rows = f2u_host(V(1)[15]);
+            const uint32_t wc = std::min(g0, cols), wr = std::min(g1, rows);
+            if (!wc || !wr) break;
+            const uint64_t npx = (uint64_t)cols * (wr - 1) + wc;
+            if ((rc = need(ctx, "pixels", BUF(0), npx * 4))) return rc;
+            if ((rc = need(ctx, "rays", BUF(2), npx * kRayBytes))) return rc;
+            if (S.id == K_a04_initTrace) pt::launch_frame_initTrace(st, false, BUF(0)->ptr, V(1), BUF(2)->ptr, nullptr, g0, g1);
+            else if (S.id == K_a07_initTrace) pt::launch_frame_initTrace(st, true, BUF(0)->ptr, V(1), BUF(2)->ptr, V(3), g0, g1);
+            else if (S.id == K_a04_meshTrace) {
+                const uint32_t T = U(3);
+                if ((rc = need(ctx, "meshTrace t_pos", BUF(4), (uint64_t)T * 48))) return rc;
+                if ((rc = need(ctx, "meshTrace t_normal", BUF(5), (uint64_t)T * 48))) return rc;
+                if ((rc = need(ctx, "meshTrace t_mindex", BUF(6), (uint64_t)T * 4))) return rc;
+                if ((rc = need(ctx, "meshTrace m_color", BUF(7), 16))) return rc;
+                if ((rc = ensure_prepared(ctx, BUF(4), T))) return rc;
+                pt::launch_a04_meshTrace(st, BUF(0)->ptr, V(1), BUF(2)->ptr, T, BUF(4)->prep, BUF(5)->ptr, BUF(6)->ptr, BUF(7)->ptr,
+                                         (uint32_t)(BUF(7)->bytes / 16), g0, g1);
+            } else {
+                if ((rc = check_grid(ctx, "meshTrace grid", BUF(10), U(9), BUF(4), 48, BUF(5), nullptr))) return rc;
+                if ((rc = ensure_prepared(ctx, BUF(4), BUF(10)->off_last))) return rc;
+                pt::launch_a07_meshTrace(st, BUF(0)->ptr, V(1), BUF(2)->ptr, BUF(4)->prep, BUF(5)->ptr, V(8), U(9), BUF(10)->ptr, g0, g1);
+            }
+            break;
+        }
         default:
             return fail(ctx, MIRT_E_NAME, "kernel not implemented");
     }
@@ -576,14 +666,7 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     o->kind = tri ? pt::KIND_TRIANGLES : pt::KIND_SPHERES;
     if (tri) {
         mirt_buf* pb = g->prims;
-        const uint32_t count = g->cell_offsets->off_last;
-        const size_t bytes = (size_t)count * 48;
-        if (pb->prep_version != pb->version || pb->prep_bytes < bytes) {
-            if (pb->prep) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pb->prep)); pb->prep = nullptr; pb->prep_bytes = 0; }
-            if (bytes) { HIPCHK(ctx, hipMalloc(&pb->prep, bytes)); pb->prep_bytes = bytes; }
-            pt::launch_prepTriangles(ctx->stream, pb->ptr, pb->prep, count);
-            pb->prep_version = pb->version;
-        }
+        if ((rc = ensure_prepared(ctx, pb, g->cell_offsets->off_last))) return rc;
         o->prims = pb->prep ? pb->prep : pb->ptr;
     }
     o->normals = tri ? g->normals->ptr : nullptr;

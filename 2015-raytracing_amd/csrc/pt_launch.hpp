@@ -69,4 +69,12 @@ void launch_fused(hipStream_t s, const FusedArgs& a);
 // {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip)
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count);
 
+// ---- single-frame kernels of Assign01 / 04 / 07 (pt_kernels_frame.hip) -----------------------------
+void launch_a01_raytrace(hipStream_t s, void* pixels, const float* cam, uint32_t gx, uint32_t gy);
+void launch_frame_initTrace(hipStream_t s, bool clip, void* pixels, const float* cam, void* rays, const float* bound, uint32_t gx, uint32_t gy);
+void launch_a04_meshTrace(hipStream_t s, void* pixels, const float* cam, void* rays, uint32_t t_size, const void* prep, const void* normals,
+                          const void* mindex, const void* mcolor, uint32_t ncolors, uint32_t gx, uint32_t gy);
+void launch_a07_meshTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* prep, const void* normals, const float* bound,
+                          uint32_t n_slabs, const void* slab_size, uint32_t gx, uint32_t gy);
+
 }  // namespace pt

@@ -1,0 +1,166 @@
+// pt_trace.hpp -- traversal of one primitive set over PREPARED geometry, shared by the fused pass
+// (pt_kernels_fused.hip) and the single-frame kernels of Assign04/07 (pt_kernels_frame.hip).
+//
+// Prepared triangle = 3 x float4 {p0.xyz, n.x} {e1.xyz, n.y} {e2.xyz, n.z} with e1 = p1-p0, e2 = p2-p0,
+// n = cross(e2,e1): the ray-independent head of the reference's Moeller-Trumbore (A10 code.cl:252-256),
+// computed once by k_prepTriangles with the same fp32 operations.
+#pragma once
+#include "pt_device.hpp"
+#include "pt_launch.hpp"
+
+namespace pt {
+
+struct Hit { uint32_t idx; float t, beta, gamma; };
+
+// Moeller-Trumbore on a prepared triangle; same operations, same order and the same
+// accept/reject predicates as inter_triangle (pt_device.hpp), written without early exits:
+// in a wave-uniform loop the 64 lanes leave at different tests anyway.
+// TRI_A10: closed t interval, no gamma > 1 test (A10 code.cl:273, 280)
+// TRI_A07: open t interval, no gamma > 1 test   (A07 code.cl:188, 195)
+// TRI_A04: open t interval, gamma > 1 rejects    (A04 code.cl:170, 177)
+enum TriRule { TRI_A10 = 0, TRI_A07 = 1, TRI_A04 = 2 };
+template <int RULE = TRI_A10>
+PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const float4 B, const float4 C,
+                     float& t_out, float& beta_out, float& gamma_out) {
+    const f3 p0 = mk3(A.x, A.y, A.z), e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z), n = mk3(A.w, B.w, C.w);
+    float div = dot3(n, d);
+    float idiv = 1.0f / div;
+    f3 s = sub3(o, p0);
+    float beta = dot3(cross3(s, d), e2) * idiv;
+    float gamma = dot3(cross3(s, e1), d) * idiv;
+    float gb = gamma + beta;
+    float t = dot3(cross3(s, e2), e1) * -idiv;
+    bool ok = !(div <= 0);
+    ok = ok && !(beta < 0.0f || beta > 1.0f);
+    if (RULE == TRI_A04) ok = ok && !(gamma < 0.0f || gamma > 1.0f || gb < 0.0f || gb > 1.0f);
+    else ok = ok && !(gamma < 0.0f || gb < 0.0f || gb > 1.0f);
+    if (RULE == TRI_A10) ok = ok && (t >= cmin && t <= cmax);
+    else ok = ok && (t > cmin && t < cmax);
+    t_out = t;
+    beta_out = beta;
+    gamma_out = gamma;
+    return ok;
+}
+
+struct SphereRay { float a, inv2a; };  // ray-only part of the quadratic (A10 code.cl:203, 218)
+PT_DEV SphereRay sphere_ray(f3 d) {
+    SphereRay r;
+    r.a = dot3(d, d);
+    r.inv2a = 1.0f / (2.0f * r.a);
+    return r;
+}
+PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, const float4 sph, float& t_out) {
+    f3 omc = sub3(o, ld3(sph));
+    float b = 2.0f * dot3(omc, d);
+    float c = dot3(omc, omc) - sph.w;
+    float dis = cl_mad(-4.0f * c, sr.a, b * b);
+    float sq = cl_sqrt(dis);
+    float t0 = (-b - sq) * sr.inv2a;
+    float t1 = (-b + sq) * sr.inv2a;
+    float tmin = cl_fmin(t0, t1);
+    float tmax = cl_fmax(t0, t1);
+    const bool in0 = (tmin >= cmin && tmin <= cmax);
+    const bool in1 = (tmax >= cmin && tmax <= cmax);
+    t_out = in0 ? tmin : tmax;
+    return !(dis < 0.0f) && (in0 || in1);
+}
+
+// One primitive set.  KIND / ANY as in pt_device.hpp.  n == 1: a single cell, every lane walks
+// the same list -> wave-uniform loop, scalar loads.  n > 1: per-lane 3-axis DDA.
+template <int KIND, bool ANY, int RULE = TRI_A10>
+PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
+    const float4* __restrict__ prims = (const float4*)S.prims;
+    const uint32_t* __restrict__ off = (const uint32_t*)S.off;
+    Hit ch;
+    ch.idx = UINT32_MAX;
+    ch.t = ray.maxt;
+    ch.beta = 0.0f;
+    ch.gamma = 0.0f;
+    SphereRay sr;
+    if (KIND == SPHERES) sr = sphere_ray(ray.d);
+
+    if (S.n == 1u) {
+        // axis_setup with n == 1: slab = 0, the cell exit is the far face as the reference computes
+        // it, lo + (0 + (d>=0)) * ((hi-lo)/1)   (A10 code.cl:699-707)
+        float tn[3];
+        if (S.exit_is_far_face) {  // host-verified: the cell's exit planes ARE the box's far planes (see mirt_abi.cpp)
+            tn[0] = bh.tfx; tn[1] = bh.tfy; tn[2] = bh.tfz;
+        } else {
+            const float lo[3] = {S.bound[0], S.bound[1], S.bound[2]}, hi[3] = {S.bound[4], S.bound[5], S.bound[6]};
+            const float oo[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float delta = (hi[k] - lo[k]) / 1.0f;
+                float xnext = lo[k] + (float)((dd[k] >= 0) ? 1 : 0) * delta;
+                tn[k] = (xnext - oo[k]) / dd[k];
+            }
+        }
+        const float cmin = bh.tmin;
+        const float cmax = cl_min(cl_min(tn[0], tn[1]), tn[2]);
+        const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
+        const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
+        bool done = false;
+        for (uint32_t i = begin; i < end; ++i) {
+            float ti, b = 0.0f, gm = 0.0f;
+            bool hit;
+            if (KIND == SPHERES) {
+                hit = sph_test(ray.o, ray.d, sr, cmin, cmax, prims[i], ti);
+            } else {
+                hit = tri_test<RULE>(ray.o, ray.d, cmin, cmax, prims[3u * i], prims[3u * i + 1], prims[3u * i + 2], ti, b, gm);
+            }
+            const bool better = !done && hit && ti < ch.t;
+            if (better) { ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm; }
+            if (ANY) {
+                done = done || better;
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every lane of the wave is blocked
+            }
+        }
+        return ch;
+    }
+
+    Axis ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n);
+    Axis ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n);
+    Axis az = axis_setup(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n);
+    float t = bh.tmin;
+    const uint32_t zs = S.n * S.n, ys = S.n;
+    for (;;) {
+        const float cmin = t;
+        const float cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+        const uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
+        const uint32_t begin = off[cell], end = off[cell + 1];
+        for (uint32_t i = begin; i < end; ++i) {
+            float ti, b = 0.0f, gm = 0.0f;
+            bool hit;
+            if (KIND == SPHERES) {
+                hit = sph_test(ray.o, ray.d, sr, cmin, cmax, prims[i], ti);
+            } else {
+                hit = tri_test<RULE>(ray.o, ray.d, cmin, cmax, prims[3u * i], prims[3u * i + 1], prims[3u * i + 2], ti, b, gm);
+            }
+            if (hit && ti < ch.t) {
+                ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm;
+                if (ANY) break;
+            }
+        }
+        if (ch.idx != UINT32_MAX) break;
+        t = cmax;
+        if (t == ax.tnext) {
+            ax.tnext += ax.dt;
+            if (t >= bh.tmax) break;
+            ax.slab += ax.dslab;
+            if (ax.slab == ax.limit) break;
+        } else if (t == ay.tnext) {
+            ay.tnext += ay.dt;
+            if (t >= bh.tmax) break;
+            ay.slab += ay.dslab;
+            if (ay.slab == ay.limit) break;
+        } else {
+            az.tnext += az.dt;
+            if (t >= bh.tmax) break;
+            az.slab += az.dslab;
+            if (az.slab == az.limit) break;
+        }
+    }
+    return ch;
+}
+
+}  // namespace pt

@@ -3,6 +3,8 @@
 //   node cli.js pack   <scene.xml> <width> <height> <raysPerPixel>                 -> packed kernel inputs as JSON (stdout)
 //   node cli.js render <scene.xml> <width> <height> <raysPerPixel> <passes> <out.rgba> [--granular] [--bounces N] [--seeds file.i32]
 //                                                                                   -> RGBA8 frame (+ <out>.radiance.f32) via the N-API addon
+//   node cli.js pack-frame <1|4|7> <mesh.json|-> <width> <height> [nSlabs]          -> packed inputs of an Assign01/04/07 frame job (stdout)
+//   node cli.js frame      <1|4|7> <mesh.json|-> <width> <height> <nSlabs|0> <out.rgba>  -> RGBA8 frame of that job
 //   node cli.js devices                                                             -> what webcl.getPlatforms()/getDevices() report
 "use strict";
 const fs = require("fs");
@@ -10,7 +12,7 @@ const path = require("path");
 const scene = require("./scene.js");
 
 function usage() {
-  process.stderr.write(fs.readFileSync(__filename, "utf8").split("\n").slice(1, 8).join("\n") + "\n");
+  process.stderr.write(fs.readFileSync(__filename, "utf8").split("\n").slice(1, 10).join("\n") + "\n");
   process.exit(2);
 }
 
@@ -34,6 +36,13 @@ if (cmd === "pack") {
   fs.writeFileSync(out, Buffer.from(res.pixel.buffer, res.pixel.byteOffset, res.pixel.byteLength));
   fs.writeFileSync(out + ".radiance.f32", Buffer.from(res.radiance.buffer, res.radiance.byteOffset, res.radiance.byteLength));
   process.stderr.write(`rendered ${file} ${w}x${h} rpp ${rpp}, ${passes} pass(es), ${opt.granular ? "kernel-by-kernel" : "fused"}: ${res.ms.toFixed(2)} ms on ${res.device}\n`);
+} else if (cmd === "pack-frame" || cmd === "frame") {
+  if (rest.length < 4) usage();
+  const frame = require("./frame.js");
+  const assign = +rest[0], model = rest[1] === "-" ? null : JSON.parse(fs.readFileSync(rest[1], "utf8").replace(/^\ufeff/, ""));
+  const p = frame.packFrame(assign, model, +rest[2], +rest[3], +rest[4] || 2);
+  if (cmd === "pack-frame") process.stdout.write(JSON.stringify(scene.packedToJSON(p)));
+  else { const px = frame.renderFrame(p); fs.writeFileSync(rest[5], Buffer.from(px.buffer, px.byteOffset, px.byteLength)); }
 } else if (cmd === "devices") {
   const { webcl } = require("./webcl.js");
   for (const p of webcl.getPlatforms()) {

@@ -63,6 +63,7 @@ SYMBOLS = {
     "mirt_buf_write": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
     "mirt_buf_read": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]),
     "mirt_program_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "mirt_program_dialect": (C.c_int, [C.c_char_p]),
     "mirt_kernel_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "mirt_kernel_release": (C.c_int, [C.c_void_p]),
     "mirt_kernel_num_args": (C.c_int, [C.c_void_p]),

@@ -204,3 +204,57 @@ class FusedRenderer:
             if b:
                 b.release()
         self.dev.release()
+
+
+class FramePacked:
+    """Packed inputs of an Assign01 / 04 / 07 frame job (what `node host/cli.js pack-frame` emits)."""
+
+    def __init__(self, d):
+        self.assign, self.width, self.height = int(d["assign"]), int(d["width"]), int(d["height"])
+        self.cam = np.asarray(d["cam"], np.float32)
+        if self.assign != 1:
+            self.bounds = np.asarray(d["bounds"], np.float32)
+            self.t_size = int(d["t_size"])
+            self.pos, self.normal = np.asarray(d["pos"], np.float32), np.asarray(d["normal"], np.float32)
+            self.mindex, self.mcolor = np.asarray(d["mindex"], np.uint32), np.asarray(d["mcolor"], np.float32)
+        if self.assign == 7:
+            self.n_slabs, self.slab_size = int(d["n_slabs"]), np.asarray(d["slab_size"], np.uint32)
+
+
+def render_frame(ctx, p):
+    """compute() of A01 (code.js:166-269) / computeTri() of A04 (code.js:553-577) and A07 (code.js:603-628) over the C ABI:
+    same kernels, argument indices and NDRange.  Returns (pixels [H*W,4] uint8, rays bytes or None)."""
+    pre = {1: "A01:", 4: "A04:", 7: "A07:"}[p.assign]
+    w, h = p.width, p.height
+    l = get_local_ws(2, 64)
+    gws = [-(-w // l[0]) * l[0], -(-h // l[1]) * l[1]]
+    pixels = ctx.buffer(w * h * 4, mirt.MEM_WRITE_ONLY)
+    keep = [pixels]
+    try:
+        if p.assign == 1:
+            k = ctx.kernel(pre + "raytrace").set_args(pixels, p.cam)
+            k.enqueue(gws, l)
+            k.release()
+            return pixels.read(np.uint8).reshape(-1, 4), None
+        k = ctx.kernel(pre + "sizeofRay")
+        tmp = ctx.buffer(4)
+        k.set_arg(0, tmp).enqueue([1], [1])
+        ray_size = int(tmp.read(np.uint32, 1)[0])
+        tmp.release(); k.release()
+        rays = ctx.buffer(w * h * ray_size)
+        up = lambda a: keep.append(ctx.buffer_from(a)) or keep[-1]
+        keep.append(rays)
+        it = ctx.kernel(pre + "initTrace").set_args(pixels, p.cam, rays)
+        if p.assign == 7:
+            it.set_arg(3, p.bounds)
+        mt = ctx.kernel(pre + "meshTrace").set_args(pixels, p.cam, rays, _u32(p.t_size), up(p.pos), up(p.normal), up(p.mindex), up(p.mcolor))
+        if p.assign == 7:
+            mt.set_arg(8, p.bounds).set_arg(9, _u32(p.n_slabs)).set_arg(10, up(p.slab_size))
+        it.enqueue(gws, l)
+        mt.enqueue(gws, l)
+        ctx.finish()
+        it.release(); mt.release()
+        return pixels.read(np.uint8).reshape(-1, 4), rays.read(np.uint8)
+    finally:
+        for b in keep:
+            b.release()

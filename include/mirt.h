@@ -92,8 +92,14 @@ MIRT_API int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* ho
  *      HIP kernel of that name exists; `missing` receives a comma-separated list of those
  *      that do not (the WebCL build log).  Returns the number of missing kernels, or <0. ---- */
 MIRT_API int mirt_program_check(mirt_ctx* ctx, const char* source, char* missing, size_t cap);
+/* Which assignment's kernel set an OpenCL C text asks for: 10 (Assign10), 7, 4, 1, or 0 = not built (A02/03/05/06/08/09).
+ * The kernel NAMES collide across assignments (initTrace, meshTrace), so the sets other than A10's are reached through
+ * mirt_kernel_get with a dialect prefix: "A07:meshTrace", "A04:initTrace", "A01:raytrace", ... */
+MIRT_API int mirt_program_dialect(const char* source);
 /* names: sizeofRay sizeofPoi initAcu initTrace sphereTrace triangleTrace meshTrace lightRender
- * initShadowTrace sphereShadowTrace triangleShadowTrace sceneRender bouncePaths copyToPixel */
+ * initShadowTrace sphereShadowTrace triangleShadowTrace sceneRender bouncePaths copyToPixel   (A10, A10 code.cl:440-1386)
+ * A07:sizeofRay A07:initTrace A07:meshTrace  (A07 code.cl:307-335, 475-626)   A04:sizeofRay A04:initTrace A04:meshTrace
+ * (A04 code.cl:200-215, 262-315)   A01:raytrace (A01 code.cl:116-147) */
 MIRT_API int mirt_kernel_get(mirt_ctx* ctx, const char* name, mirt_kernel** out);
 MIRT_API int mirt_kernel_release(mirt_kernel* k);
 /* number of arguments of the kernel (WebCL kernel.getInfo(KERNEL_NUM_ARGS)) */

@@ -1,0 +1,73 @@
+"""oracle/frame_pass.py -- TEST INFRASTRUCTURE (checker only).
+
+Drives a CPU implementation of the single-frame kernels of Assign01 / Assign04 / Assign07 in the order the
+reference host enqueues them (A01 code.js:166-269 compute; A04 code.js:553-577 / A07 code.js:603-628 computeTri:
+initTrace, meshTrace, read back).  Implementations: oracle/_ref/libref_a0N.so (the reference's own code.cl compiled
+for x86, build container only) and oracle/liboracle.so (our restatement).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+import a10_pass as A
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _lib(kind, assign):
+    if kind == "ref":
+        return C.CDLL(os.path.join(HERE, "_ref", f"libref_a{assign:02d}.so")), f"ref_a{assign:02d}_"
+    return C.CDLL(os.path.join(HERE, "liboracle.so")), f"oracle_a{assign:02d}_"
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, np.float32)
+    return a.ctypes.data_as(C.POINTER(C.c_float)), a
+
+
+class Frame:
+    """Packed inputs of one frame job (the JSON of gen/ref_host_dump_frame.js or of our JS host's `frame` packer)."""
+
+    def __init__(self, d):
+        self.d = d
+        self.assign, self.width, self.height = int(d["assign"]), int(d["width"]), int(d["height"])
+        self.cam = np.asarray(d["cam"], np.float32)
+        if self.assign != 1:
+            self.bounds = np.asarray(d["bounds"], np.float32)
+            self.t_size = int(d["t_size"])
+            self.pos, self.normal = np.asarray(d["pos"], np.float32), np.asarray(d["normal"], np.float32)
+            self.mindex, self.mcolor = np.asarray(d["mindex"], np.uint32), np.asarray(d["mcolor"], np.float32)
+        if self.assign == 7:
+            self.n_slabs, self.slab_size = int(d["n_slabs"]), np.asarray(d["slab_size"], np.uint32)
+
+
+def run_frame(kind, fr):
+    """Returns (pixels uint8 [H*W,4], rays structured [H*W] or None)."""
+    lib, pre = _lib(kind, fr.assign)
+    w, h = fr.width, fr.height
+    gx, gy = A._ceil(w, 8), A._ceil(h, 8)          # getLocalWS(2, 64) = [8, 8]
+    pixels = np.zeros((w * h, 4), np.uint8)
+    cp, _c = _f(fr.cam)
+    sz, vp, fp, u = C.c_size_t, C.c_void_p, C.POINTER(C.c_float), C.c_uint
+    if fr.assign == 1:
+        f = getattr(lib, pre + "raytrace"); f.argtypes = [vp, fp, sz, sz]; f.restype = None
+        f(_p(pixels), cp, w, h)                    # exactly cols x rows: the reference kernel has no range check
+        return pixels, None
+    rays = np.zeros(w * h, A.RAY_DT)
+    if fr.assign == 4:
+        f = getattr(lib, pre + "initTrace"); f.argtypes = [vp, fp, vp, sz, sz]; f.restype = None
+        f(_p(pixels), cp, _p(rays), gx, gy)
+        f = getattr(lib, pre + "meshTrace"); f.argtypes = [vp, fp, vp, u, vp, vp, vp, vp, sz, sz]; f.restype = None
+        f(_p(pixels), cp, _p(rays), fr.t_size, _p(fr.pos), _p(fr.normal), _p(fr.mindex), _p(fr.mcolor), gx, gy)
+    else:
+        bp, _b = _f(fr.bounds)
+        f = getattr(lib, pre + "initTrace"); f.argtypes = [vp, fp, vp, fp, sz, sz]; f.restype = None
+        f(_p(pixels), cp, _p(rays), bp, gx, gy)
+        f = getattr(lib, pre + "meshTrace"); f.argtypes = [vp, fp, vp, u, vp, vp, vp, vp, fp, u, vp, sz, sz]; f.restype = None
+        f(_p(pixels), cp, _p(rays), fr.t_size, _p(fr.pos), _p(fr.normal), _p(fr.mindex), _p(fr.mcolor), bp, fr.n_slabs, _p(fr.slab_size), gx, gy)
+    return pixels, rays

@@ -48,8 +48,10 @@ void oracle_set_threads(int n) {
 
 #if defined(_OPENMP) && !defined(PTO_COUNT_FLOPS)
 #define PAR_FOR _Pragma("omp parallel for schedule(static, 4096)")
+#define PAR_ROWS _Pragma("omp parallel for schedule(dynamic, 1)")
 #else
 #define PAR_FOR
+#define PAR_ROWS
 #endif
 
 /* ---- small vector layer -------------------------------------------------- */
@@ -650,3 +652,184 @@ void oracle_a10_copyToPixel(void* pixel_, void* acu_, float m, unsigned pixels, 
 
 float oracle_bi_sin(float x) { return cln_sin(x); }
 float oracle_bi_cos(float x) { return cln_cos(x); }
+
+/* ========================================================================== *
+ *  Single-frame kernels of the earlier assignments (BASELINE configs 1-3).   *
+ *  "A01/A04/A07 code.cl:NNN" = AssignNN-*\/code.cl.                          *
+ * ========================================================================== */
+
+/* (uchar) of a float as the compiled reference does it: truncate to int32, keep the low byte */
+static inline uint8_t f2u8(float f) { return (uint8_t)(cln_f2i(f) & 0xFF); }
+
+/* A01 code.cl:116-147 with getRay :48-59 and interSphere :61-91.  The camera carries rows, cols as FLOATS
+ * in .sE, .sF (swapped w.r.t. A02+).  The reference has no range check; it is launched on a padded NDRange
+ * and relies on width/height being multiples of the work-group shape.  We skip out-of-image work-items. */
+void oracle_a01_raytrace(void* pixels_, const float* cam, size_t gx, size_t gy) {
+    uint8_t* pixels = (uint8_t*)pixels_;
+    const v3 eye = ld3(cam), U = ld3(cam + 3), Vv = ld3(cam + 6), W = ld3(cam + 9);
+    const float width = cam[12], height = cam[13], rows = cam[14], cols = cam[15];
+    const uint32_t ucols = cln_f2u(cols);
+    for (size_t row = 0; row < gy; ++row)
+        for (size_t col = 0; col < gx; ++col) {
+            if (!((float)col < cols) || !((float)row < rows)) continue;
+            float sx = (-0.5f + ((float)(uint32_t)col + 0.5f) / cols) * width;
+            float sy = (0.5f - ((float)(uint32_t)row + 0.5f) / rows) * height;
+            v3 cop = add(add(scl(sx, U), scl(sy, Vv)), scl(-1.0f, W));
+            v3 o = eye;
+            v3 d = norm3(sub(cop, o));
+            const v3 sc = V(0.0f, 0.0f, 1.0f);
+            const float sr = 0.5f;
+            v3 omc = sub(o, sc);
+            float a = dot3(d, d);
+            float b = 2.0f * dot3(omc, d);
+            float c = dot3(omc, omc) - sr * sr;
+            float dis = b * b - 4.0f * a * c;
+            int v = 0;
+            float t = PT_INF;
+            if (!(dis < 0.0f)) {
+                float sq = cln_sqrt(dis);
+                float t0 = (-b - sq) / 2 * a;   /* sic: (x / 2) * a */
+                float t1 = (-b + sq) / 2 * a;
+                if (t0 > 0.0f && t0 < PT_INF) { t = t0; v = 1; }
+                else if (t1 > 0.0f && t1 < PT_INF) { t = t1; v = 1; }
+            }
+            uint8_t base = v ? f2u8((1.0f - t) * 255.0f) : 0;
+            uint8_t* px = pixels + 4u * ((size_t)ucols * row + col);
+            px[0] = base; px[1] = base; px[2] = base; px[3] = 255;
+        }
+}
+
+/* A04 code.cl:86-97 == A07 code.cl:97-108: pinhole ray through the pixel centre */
+static ray_t pinhole_ray(const cam_t* c, float col, float row) { return get_ray(c, col, row); }
+
+/* A04 code.cl:204-215 (clip = 0) and A07 code.cl:311-335 (clip = 1) */
+static void frame_init(uint8_t* pixels, const float* cam16, pto_ray* rays, const float* bound8, size_t gx, size_t gy, int clip) {
+    cam_t cam = ld_cam(cam16);
+    box_t bound;
+    if (clip) bound = ld_box(bound8);
+    for (size_t row = 0; row < gy; ++row)
+        for (size_t col = 0; col < gx; ++col) {
+            if (col >= cam.cols || row >= cam.rows) continue;
+            ray_t r = pinhole_ray(&cam, (float)(uint32_t)col, (float)(uint32_t)row);
+            size_t pix = (size_t)cam.cols * row + col;
+            if (clip) clip_and_store(&rays[pix], r, &bound); else st_ray(&rays[pix], r);
+            pixels[4 * pix + 0] = 0; pixels[4 * pix + 1] = 0; pixels[4 * pix + 2] = 0; pixels[4 * pix + 3] = 255;
+        }
+}
+void oracle_a04_initTrace(void* pixels, const float* cam, void* rays, size_t gx, size_t gy) {
+    frame_init((uint8_t*)pixels, cam, (pto_ray*)rays, NULL, gx, gy, 0);
+}
+void oracle_a07_initTrace(void* pixels, const float* cam, void* rays, const float* bound, size_t gx, size_t gy) {
+    frame_init((uint8_t*)pixels, cam, (pto_ray*)rays, bound, gx, gy, 1);
+}
+
+/* interTriangle of A04 (code.cl:146-184: gamma > 1 also rejects) and A07 (code.cl:165-203); both accept t in the
+ * OPEN interval (mint, maxt), unlike A10 */
+static int inter_triangle_open(const ray_t* r, const float* tp, int gamma_le_1, float* t_out, float* beta_out, float* gamma_out) {
+    v3 p0 = ld3(tp), p1 = ld3(tp + 4), p2 = ld3(tp + 8);
+    v3 e1 = sub(p1, p0);
+    v3 e2 = sub(p2, p0);
+    float div = dot3(cross3(e2, e1), r->d);
+    if (div <= 0) return 0;
+    float idiv = 1.0f / div;
+    v3 s = sub(r->o, p0);
+    float beta = dot3(cross3(s, r->d), e2) * idiv;
+    if (beta < 0.0f || beta > 1.0f) return 0;
+    float gamma = dot3(cross3(s, e1), r->d) * idiv;
+    float gb = gamma + beta;
+    if (gamma < 0.0f || (gamma_le_1 && gamma > 1.0f) || gb < 0.0f || gb > 1.0f) return 0;
+    float t = dot3(cross3(s, e2), e1) * -idiv;
+    if (t > r->mint && t < r->maxt) { *t_out = t; *beta_out = beta; *gamma_out = gamma; return 1; }
+    return 0;
+}
+static v3 interp_normal(const float* normals, uint32_t i, float beta, float gamma) {
+    const float* nn = normals + 12u * (size_t)i;
+    float w = 1.0f - beta - gamma;
+    return norm3(add(add(scl(w, ld3(nn)), scl(beta, ld3(nn + 4))), scl(gamma, ld3(nn + 8))));
+}
+
+/* A04 code.cl:262-315: every pixel against every triangle */
+void oracle_a04_meshTrace(void* pixels_, const float* cam16, void* rays_, unsigned t_size, void* pos_, void* nor_, unsigned* mindex,
+                          void* mcolor_, size_t gx, size_t gy) {
+    uint8_t* pixels = (uint8_t*)pixels_;
+    pto_ray* rays = (pto_ray*)rays_;
+    const float *pos = (const float*)pos_, *nor = (const float*)nor_, *mcolor = (const float*)mcolor_;
+    cam_t cam = ld_cam(cam16);
+    const long rows = (long)(gy < cam.rows ? gy : cam.rows);
+    const size_t cols = gx < cam.cols ? gx : cam.cols;
+    PAR_ROWS
+    for (long row = 0; row < rows; ++row)
+        for (size_t col = 0; col < cols; ++col) {
+            size_t pix = (size_t)cam.cols * (size_t)row + col;
+            ray_t ray = ld_ray(&rays[pix]);
+            float champ_t = PT_INF, cb = 0.0f, cg = 0.0f;
+            unsigned champ_i = t_size;
+            for (unsigned i = 0; i < t_size; ++i) {
+                float t, b, g;
+                if (inter_triangle_open(&ray, pos + 12u * (size_t)i, 1, &t, &b, &g) && t < champ_t) { champ_t = t; champ_i = i; cb = b; cg = g; }
+            }
+            if (champ_i >= t_size) continue;
+            rays[pix].maxt = champ_t;
+            v3 n = interp_normal(nor, champ_i, cb, cg);
+            float shade = cln_clamp(dot3(cam.W, n), 0.0f, 1.0f);
+            const float* mc = mcolor + 4u * (size_t)mindex[champ_i];
+            pixels[4 * pix + 0] = f2u8((mc[0] * 255.0f) * shade);
+            pixels[4 * pix + 1] = f2u8((mc[1] * 255.0f) * shade);
+            pixels[4 * pix + 2] = f2u8((mc[2] * 255.0f) * shade);
+            pixels[4 * pix + 3] = 255;
+        }
+}
+
+/* A07 code.cl:475-626: 3-D grid DDA (same walk as A10), colour = parity of the hit cell x fake shade */
+void oracle_a07_meshTrace(void* pixels_, const float* cam16, void* rays_, unsigned t_size, void* pos_, void* nor_, unsigned* mindex,
+                          void* mcolor, const float* bound8, unsigned n_slabs, unsigned* slab_size, size_t gx, size_t gy) {
+    (void)t_size; (void)mindex; (void)mcolor;   /* bound by the host, unused by the kernel's live code */
+    uint8_t* pixels = (uint8_t*)pixels_;
+    pto_ray* rays = (pto_ray*)rays_;
+    const float *pos = (const float*)pos_, *nor = (const float*)nor_;
+    cam_t cam = ld_cam(cam16);
+    box_t bound = ld_box(bound8);
+    const long rows = (long)(gy < cam.rows ? gy : cam.rows);
+    const size_t cols = gx < cam.cols ? gx : cam.cols;
+    const uint32_t n = n_slabs, zs = n * n, ys = n;
+    PAR_ROWS
+    for (long row = 0; row < rows; ++row)
+        for (size_t col = 0; col < cols; ++col) {
+            size_t pix = (size_t)cam.cols * (size_t)row + col;
+            ray_t ray = ld_ray(&rays[pix]);
+            if (ray.mint == ray.maxt) continue;
+            boxhit_t bh = inter_aabb(&ray, &bound);
+            if (!bh.v) continue;
+            axis_t ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, bound.pmin.x, bound.pmax.x, n);
+            axis_t ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, bound.pmin.y, bound.pmax.y, n);
+            axis_t az = axis_setup(ray.o.z, ray.d.z, bh.tmin, bound.pmin.z, bound.pmax.z, n);
+            float champ_t = ray.maxt, cb = 0.0f, cg = 0.0f, t = bh.tmin;
+            uint32_t champ_i = UINT_MAX;
+            int hx = 0, hy = 0, hz = 0;
+            for (;;) {
+                ray.mint = t;
+                ray.maxt = cln_min(cln_min(ax.tnext, ay.tnext), az.tnext);
+                uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
+                for (uint32_t i = slab_size[cell]; i < slab_size[cell + 1]; ++i) {
+                    float ti, b, g;
+                    if (inter_triangle_open(&ray, pos + 12u * (size_t)i, 0, &ti, &b, &g) && ti < champ_t) {
+                        champ_t = ti; champ_i = i; cb = b; cg = g; hx = ax.slab; hy = ay.slab; hz = az.slab;
+                    }
+                }
+                if (champ_i != UINT_MAX) break;
+                t = ray.maxt;
+                if (t == ax.tnext) { ax.tnext += ax.dt; if (t >= bh.tmax) break; ax.slab += ax.dslab; if (ax.slab == ax.limit) break; }
+                else if (t == ay.tnext) { ay.tnext += ay.dt; if (t >= bh.tmax) break; ay.slab += ay.dslab; if (ay.slab == ay.limit) break; }
+                else { az.tnext += az.dt; if (t >= bh.tmax) break; az.slab += az.dslab; if (az.slab == az.limit) break; }
+            }
+            if (champ_i == UINT_MAX) continue;
+            rays[pix].maxt = champ_t;
+            v3 nrm = interp_normal(nor, champ_i, cb, cg);
+            float shade = cln_clamp(dot3(cam.W, nrm), 0.0f, 1.0f);
+            float k = shade * 127.0f;
+            pixels[4 * pix + 0] = f2u8((float)((hx % 2) + 1) * k);
+            pixels[4 * pix + 1] = f2u8((float)((hy % 2) + 1) * k);
+            pixels[4 * pix + 2] = f2u8((float)((hz % 2) + 1) * k);
+            pixels[4 * pix + 3] = 255;
+        }
+}

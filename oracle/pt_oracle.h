@@ -50,6 +50,15 @@ void oracle_a10_sceneRender(void* acu, void* pois, void* shadow, void* material,
                             unsigned total, size_t gsz);
 void oracle_a10_copyToPixel(void* pixel, void* acu, float m, unsigned pixels, unsigned rpp, size_t gsz);
 
+/* single-frame kernels of Assign01 / 04 / 07 (BASELINE configs 1-3) */
+void oracle_a01_raytrace(void* pixels, const float* cam, size_t gx, size_t gy);
+void oracle_a04_initTrace(void* pixels, const float* cam, void* rays, size_t gx, size_t gy);
+void oracle_a04_meshTrace(void* pixels, const float* cam, void* rays, unsigned t_size, void* pos, void* nor, unsigned* mindex,
+                          void* mcolor, size_t gx, size_t gy);
+void oracle_a07_initTrace(void* pixels, const float* cam, void* rays, const float* bound, size_t gx, size_t gy);
+void oracle_a07_meshTrace(void* pixels, const float* cam, void* rays, unsigned t_size, void* pos, void* nor, unsigned* mindex,
+                          void* mcolor, const float* bound, unsigned n_slabs, unsigned* slab_size, size_t gx, size_t gy);
+
 /* built-in probes (tests compare them with the functions the compiled reference called) */
 float oracle_bi_sin(float x);
 float oracle_bi_cos(float x);

@@ -221,3 +221,58 @@ float ref_bi_sin(float x) { return cl_sin(x); }
 float ref_bi_cos(float x) { return cl_cos(x); }
 }  // extern "C"
 #endif  // REF_A10
+
+// ---- single-frame kernels of the earlier assignments: 2-D NDRange, row-major work-item order ----
+#define FOR_2D(gx, gy) for (size_t _r = 0; _r < (size_t)(gy); ++_r) for (size_t _c = 0; _c < (size_t)(gx); ++_c) \
+    if ((g_gid[0] = _c, g_gid[1] = _r, g_gid[2] = 0, true))
+
+#ifdef REF_A01
+extern "C" {
+void __clang_ocl_kern_imp_raytrace(uchar4*, float16);
+// the reference kernel has no range check: launch it on exactly cols x rows (the reference pads the NDRange and
+// relies on the canvas being a multiple of the work-group shape, A01 code.js:237-241)
+void ref_a01_raytrace(void* pixels, const float* cam, size_t gx, size_t gy) {
+    float16 c = mk16(cam);
+    FOR_2D(gx, gy) __clang_ocl_kern_imp_raytrace((uchar4*)pixels, c);
+}
+}
+#endif
+
+#ifdef REF_A04
+extern "C" {
+void __clang_ocl_kern_imp_sizeofRay(unsigned*);
+void __clang_ocl_kern_imp_initTrace(uchar4*, float16, Ray*);
+void __clang_ocl_kern_imp_meshTrace(uchar4*, float16, Ray*, unsigned, float3*, float3*, unsigned*, float4*);
+unsigned ref_a04_sizeofRay(void) { unsigned s = 0; g_gid[0] = 0; __clang_ocl_kern_imp_sizeofRay(&s); return s; }
+void ref_a04_initTrace(void* pixels, const float* cam, void* rays, size_t gx, size_t gy) {
+    float16 c = mk16(cam);
+    FOR_2D(gx, gy) __clang_ocl_kern_imp_initTrace((uchar4*)pixels, c, (Ray*)rays);
+}
+void ref_a04_meshTrace(void* pixels, const float* cam, void* rays, unsigned t_size, void* pos, void* nor, unsigned* mindex,
+                       void* mcolor, size_t gx, size_t gy) {
+    float16 c = mk16(cam);
+    FOR_2D(gx, gy) __clang_ocl_kern_imp_meshTrace((uchar4*)pixels, c, (Ray*)rays, t_size, (float3*)pos, (float3*)nor, mindex, (float4*)mcolor);
+}
+}
+#endif
+
+#ifdef REF_A07
+extern "C" {
+void __clang_ocl_kern_imp_sizeofRay(unsigned*);
+void __clang_ocl_kern_imp_initTrace(uchar4*, float16, Ray*, AABB);
+void __clang_ocl_kern_imp_meshTrace(uchar4*, float16, Ray*, unsigned, float3*, float3*, unsigned*, float4*, AABB, unsigned, unsigned*);
+unsigned ref_a07_sizeofRay(void) { unsigned s = 0; g_gid[0] = 0; __clang_ocl_kern_imp_sizeofRay(&s); return s; }
+void ref_a07_initTrace(void* pixels, const float* cam, void* rays, const float* bound, size_t gx, size_t gy) {
+    float16 c = mk16(cam);
+    AABB b = mkbox(bound);
+    FOR_2D(gx, gy) __clang_ocl_kern_imp_initTrace((uchar4*)pixels, c, (Ray*)rays, b);
+}
+void ref_a07_meshTrace(void* pixels, const float* cam, void* rays, unsigned t_size, void* pos, void* nor, unsigned* mindex,
+                       void* mcolor, const float* bound, unsigned n_slabs, unsigned* slab_size, size_t gx, size_t gy) {
+    float16 c = mk16(cam);
+    AABB b = mkbox(bound);
+    FOR_2D(gx, gy) __clang_ocl_kern_imp_meshTrace((uchar4*)pixels, c, (Ray*)rays, t_size, (float3*)pos, (float3*)nor, mindex, (float4*)mcolor,
+                                                  b, n_slabs, slab_size);
+}
+}
+#endif
