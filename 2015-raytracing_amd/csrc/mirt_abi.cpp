@@ -676,6 +676,12 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     o->n = g->n_slabs;
     o->mesh_matid = g->mesh_matid;
     o->exit_is_far_face = 0;
+    o->bounds_sane = 1;
+    for (int k = 0; k < 8; ++k) {
+        if ((k & 3) == 3) continue;
+        const float a = std::fabs(g->bounds[k]);
+        if (!(a == 0.0f || (a >= 9.3132257e-10f && a <= 1048576.0f))) o->bounds_sane = 0;
+    }
     if (g->n_slabs == 1) {
         // A10 code.cl:699-707 with n = 1: x_next = pmin + (0 + (d>=0)) * ((pmax-pmin)/1).  When that reproduces pmax / pmin
         // bit for bit, t_next is the very quotient interAABB already formed for the far slab plane.
@@ -808,6 +814,19 @@ int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_bu
     if (!b && (op == 0 || (op >= 6 && op <= 12))) return fail(ctx, MIRT_E_ARG, "mirt_debug_numerics: op %d needs two inputs", op);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pt::launch_numerics(ctx->stream, op, a->ptr, b ? b->ptr : nullptr, out->ptr, n);
+    HIPCHK(ctx, hipGetLastError());
+    return MIRT_OK;
+}
+
+int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_divcheck: unknown context");
+    int rc = need(ctx, "mirt_debug_divcheck out", out16, 16 * 8);
+    if (rc) return rc;
+    if (mode < 0 || mode > 3) return fail(ctx, MIRT_E_ARG, "mirt_debug_divcheck: mode is 0..3");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(out16->ptr, 0, 16 * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync((char*)out16->ptr + 80, 0xFF, 8, ctx->stream));   // out[10]: running minimum
+    pt::launch_divCheck(ctx->stream, mode, seed, count, out16->ptr);
     HIPCHK(ctx, hipGetLastError());
     return MIRT_OK;
 }

@@ -31,7 +31,7 @@ PT_DEV f3 cross3(f3 a, f3 b) {
 }
 PT_DEV float len3(f3 a) { return cl_sqrt(dot3(a, a)); }
 PT_DEV f3 norm3(f3 a) {
-    float inv = 1.0f / cl_sqrt(dot3(a, a));
+    float inv = rcp_exact(cl_sqrt(dot3(a, a)));
     return mk3(a.x * inv, a.y * inv, a.z * inv);
 }
 PT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }

@@ -40,6 +40,30 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
     out[3u * i + 2] = make_float4(e2.x, e2.y, e2.z, n.z);
 }
 
+// Cold per-ray state parked in LDS instead of registers: the accumulator (touched once per shading event) and the
+// path attenuation (once per shade).  Seven dwords per lane = 7 KB per 256-thread block, [word][lane] so a wave's
+// access is one conflict-free row.  It buys the register allocator seven VGPRs on a kernel that is held at
+// 6 waves/SIMD by an 80-register budget.
+#ifndef PT_PARK_LDS
+#define PT_PARK_LDS 1
+#endif
+#ifndef PT_PARK_PN
+#define PT_PARK_PN 0   // A/B: parking p and n as well is slower (199.9 vs 196.2 ms): the reloads sit on the critical path
+#endif
+#define PT_PARK_WORDS (PT_PARK_PN ? 13 : 7)
+struct Park {
+#if PT_PARK_LDS
+    float* base;   // &park[0][threadIdx.x]
+    PT_DEV void put(int w, float v) const { base[w * 256] = v; }
+    PT_DEV float get(int w) const { return base[w * 256]; }
+    PT_DEV void acc_add(float x, float y, float z) const {
+        put(0, get(0) + x); put(1, get(1) + y); put(2, get(2) + z); put(3, get(3) + 1.0f);
+    }
+    PT_DEV void put_pn(const Poi& q) const { put(7, q.p.x); put(8, q.p.y); put(9, q.p.z); put(10, q.n.x); put(11, q.n.y); put(12, q.n.z); }
+    PT_DEV void get_pn(Poi& q) const { q.p = mk3(get(7), get(8), get(9)); q.n = mk3(get(10), get(11), get(12)); }
+#endif
+};
+
 PT_DEV Box set_box(const GridArgs& S) {
     Box b;
     b.lo = mk3(S.bound[0], S.bound[1], S.bound[2]);
@@ -49,11 +73,12 @@ PT_DEV Box set_box(const GridArgs& S) {
 
 // closest hit over every set in upload order, z-buffered through ray.maxt
 // (A10 code.cl:675-800, 802-935, 937-1070; order A10 code.js:1809-1813)
-PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi) {
+PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park) {
+    const RayRecip rr = ray_recip(ray);
     for (uint32_t s = 0; s < A.n_sets; ++s) {
         const GridArgs& S = A.sets[s];
         if (ray.mint == ray.maxt) continue;
-        BoxHit bh = inter_aabb(ray, set_box(S));
+        BoxHit bh = inter_aabb_rr(ray, set_box(S), rr, S.bounds_sane != 0);
         if (!bh.v) continue;
         if (S.kind == KIND_SPHERES) {
             Hit ch = trace_set<SPHERES, false>(ray, bh, S);
@@ -62,6 +87,9 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi) {
             poi.p = add3(ray.o, scl3(ch.t, ray.d));
             poi.n = norm3(sub3(poi.p, ld3(((const float4*)S.prims)[ch.idx])));
             poi.matId = (int32_t)((const uint32_t*)S.matid)[ch.idx];
+#if PT_PARK_LDS && PT_PARK_PN
+            park.put_pn(poi);
+#endif
         } else {
             Hit ch = trace_set<TRIANGLES, false>(ray, bh, S);
             if (ch.idx == UINT32_MAX) continue;
@@ -71,22 +99,29 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi) {
             float w = 1.0f - ch.beta - ch.gamma;  // code.cl:409-411
             poi.n = norm3(add3(add3(scl3(w, ld3(nn[0])), scl3(ch.beta, ld3(nn[1]))), scl3(ch.gamma, ld3(nn[2]))));
             poi.matId = (int32_t)(S.matid ? ((const uint32_t*)S.matid)[ch.idx] : S.mesh_matid);
+#if PT_PARK_LDS && PT_PARK_PN
+            park.put_pn(poi);
+#endif
         }
     }
 }
 
 // per light: shadow ray, any-hit over every set, shade (A10 code.js:1817-1826; code.cl:631-673,
 // 1073-1321, 1323-1364)
-PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc) {
+PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc, const Park& park) {
     const float4* material = (const float4*)A.material;
     for (uint32_t l = 0; l < A.n_lights; ++l) {
         const LightArgs& L = A.lights[l];
         if (poi.matId < 0) continue;  // initShadowTrace: a dead path draws nothing (code.cl:645-650)
+#if PT_PARK_LDS && PT_PARK_PN
+        park.get_pn(poi);
+#endif
         Ray sh = shadow_ray(poi, ld3(L.shadow), ld3(L.shadow + 3), ld3(L.shadow + 6), L.shadow[9], seed);
+        const RayRecip rr = ray_recip(sh);
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
             if (sh.mint == sh.maxt) continue;
-            BoxHit bh = inter_aabb(sh, set_box(S));
+            BoxHit bh = inter_aabb_rr(sh, set_box(S), rr, S.bounds_sane != 0);
             if (!bh.v) continue;
             Hit ch = (S.kind == KIND_SPHERES) ? trace_set<SPHERES, true>(sh, bh, S) : trace_set<TRIANGLES, true>(sh, bh, S);
             sh.maxt = ch.t;
@@ -94,8 +129,18 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc)
         }
         if ((uint32_t)poi.matId >= A.nmat) continue;  // out-of-range id: shade nothing (see k_sceneRender)
         float4 c4 = material[poi.matId];
+#if PT_PARK_LDS
+#if PT_PARK_PN
+        park.get_pn(poi);
+#endif
+        poi.atte = mk3(park.get(4), park.get(5), park.get(6));
+        f3 c = shade_vertex(poi, sh, mk3(c4.x, c4.y, c4.z), ld3(L.scene), ld3(L.scene + 3), ld3(L.scene + 6), L.scene[9]);
+        park.put(4, poi.atte.x); park.put(5, poi.atte.y); park.put(6, poi.atte.z);
+        park.acc_add(c.x, c.y, c.z);
+#else
         f3 c = shade_vertex(poi, sh, mk3(c4.x, c4.y, c4.z), ld3(L.scene), ld3(L.scene + 3), ld3(L.scene + 6), L.scene[9]);
         acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
+#endif
     }
 }
 
@@ -122,6 +167,13 @@ __global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedAr
 
     int32_t seed = A.seeds[lid];
     float4 acc = ((const float4*)A.acu)[lid];
+    Park park;
+#if PT_PARK_LDS
+    __shared__ float park_mem[PT_PARK_WORDS][256];
+    park.base = &park_mem[0][threadIdx.x];
+    park.put(0, acc.x); park.put(1, acc.y); park.put(2, acc.z); park.put(3, acc.w);
+    park.put(4, 1.0f); park.put(5, 1.0f); park.put(6, 1.0f);
+#endif
 
     // ---- initTrace (code.cl:458-543) for this one ray
     f3 fp = focal_point(cam, (float)col, (float)row, A.focal_length);
@@ -153,13 +205,16 @@ __global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedAr
     for (uint32_t seg = 0; seg <= A.bounces; ++seg) {
         if (seg > 0) {
             if (poi.matId >= 0) {
+#if PT_PARK_LDS && PT_PARK_PN
+                park.get_pn(poi);
+#endif
                 ray = bounce_ray(poi, seed);
             } else {
                 ray.mint = PT_INF;
                 ray.maxt = PT_INF;
             }
         }
-        closest_all(A, ray, poi);
+        closest_all(A, ray, poi, park);
         if (seg == 0) {
             for (uint32_t l = 0; l < A.n_lights; ++l) {  // lightRender (code.cl:600-629), primary segment only
                 if (ray.mint == ray.maxt) continue;
@@ -169,13 +224,20 @@ __global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedAr
                 ray.mint = PT_INF;
                 ray.maxt = PT_INF;
                 poi.matId = -1;
+#if PT_PARK_LDS
+                park.acc_add(irr.x, irr.y, irr.z);
+#else
                 acc.x += irr.x; acc.y += irr.y; acc.z += irr.z; acc.w += 1.0f;
+#endif
             }
         }
-        direct_all(A, poi, seed, acc);
+        direct_all(A, poi, seed, acc, park);
     }
 
     A.seeds[lid] = seed;
+#if PT_PARK_LDS
+    acc = make_float4(park.get(0), park.get(1), park.get(2), park.get(3));
+#endif
     ((float4*)A.acu)[lid] = acc;
 }
 

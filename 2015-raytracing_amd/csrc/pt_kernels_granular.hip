@@ -283,6 +283,61 @@ __global__ void __launch_bounds__(256) k_numerics(int op, const float* a, const 
     out[i] = r;
 }
 
+// Diagnostic: counts, over `count` pseudo-random (n, d) pairs inside the guard window, how often the
+// shared-reciprocal forms differ from the compiler's correctly rounded division.
+//   out[0] div_shared(n,d,rcp_refined(d)) != n/d     out[1] rcp_refined(d) != 1/d
+//   out[2] div_shared(1,d,r) != 1/d                  out[3] 3-op form (one refinement) != n/d
+//   out[4..7] bit patterns (n, d) of the first mismatch of kind 0 / kind 3      out[12] div_exact3(n,d,r) != n/d (the form the kernels use)
+// mode 0: random mantissas and exponents; mode 1: d sweeps EVERY mantissa (count = 2^23 * exponents), n random;
+// mode 2: as 0 without the zero numerators
+__global__ void __launch_bounds__(256) k_divCheck(int mode, uint64_t seed, uint64_t count, unsigned long long* out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+    if (mode == 3) {
+        // every one of the 2^32 bit patterns as a denominator: rcp_refined(d) against 1.0f/d (NaN == NaN);
+        // out[1] = mismatches, out[10]/out[11] = smallest / largest |d| bit pattern that mismatched
+        unsigned long long lo = ~0ull, hi = 0;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+            const float d = __uint_as_float((uint32_t)i);
+            const float a = rcp_refined(d), b = 1.0f / d;
+            const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
+            if (!same) { ++m1; const unsigned long long k = (uint32_t)i & 0x7FFFFFFFu; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+        }
+        if (m1) { atomicAdd(&out[1], m1); atomicMin(&out[10], lo); atomicMax(&out[11], hi); }
+        return;
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        uint64_t h = (i + seed) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+        uint32_t dm, de;
+        if (mode == 1) { dm = (uint32_t)(i & 0x7FFFFFu); de = 127u - 40u + (uint32_t)((i >> 23) % 81u); }
+        else { dm = (uint32_t)(h & 0x7FFFFFu); de = 127u - 40u + (uint32_t)((h >> 23) % 81u); }
+        const uint32_t ds = (uint32_t)(h >> 31) & 0x80000000u;
+        const float d = __uint_as_float(ds | (de << 23) | dm);
+        const uint32_t nm = (uint32_t)(h >> 32) & 0x7FFFFFu, ne = 127u - 60u + (uint32_t)((h >> 55) % 121u);
+        const uint32_t ns = (uint32_t)(h >> 8) & 0x80000000u;
+        float n = __uint_as_float(ns | (ne << 23) | nm);
+        if (mode != 2 && (h & 0xFFF000000ull) == 0) n = __uint_as_float(ns);   // sprinkle +-0 numerators (not in mode 2)
+        const float ref = n / d;
+        const float r = rcp_refined(d);
+        const float q = div_shared(n, d, r);
+        const float inv = 1.0f / d;
+        const float q1 = div_shared(1.0f, d, r);
+        float q3 = n * r;
+        q3 = __builtin_fmaf(__builtin_fmaf(-d, q3, n), r, q3);
+        if (__float_as_uint(div_exact3(n, d, r)) != __float_as_uint(ref)) ++m4;
+        if (__float_as_uint(q) != __float_as_uint(ref)) { if (!m0 && !atomicAdd(&out[8], 1ull)) { out[4] = __float_as_uint(n); out[5] = __float_as_uint(d); } ++m0; }
+        if (__float_as_uint(r) != __float_as_uint(inv)) ++m1;
+        if (__float_as_uint(q1) != __float_as_uint(inv)) ++m2;
+        if (__float_as_uint(q3) != __float_as_uint(ref)) { if (!m3 && !atomicAdd(&out[9], 1ull)) { out[6] = __float_as_uint(n); out[7] = __float_as_uint(d); } ++m3; }
+    }
+    if (m0) atomicAdd(&out[0], m0);
+    if (m1) atomicAdd(&out[1], m1);
+    if (m2) atomicAdd(&out[2], m2);
+    if (m3) atomicAdd(&out[3], m3);
+    if (m4) atomicAdd(&out[12], m4);
+}
+
 }  // namespace pt
 
 // ---- launchers (C++ linkage, called by the C-ABI layer) -----------------------------------
@@ -359,6 +414,9 @@ void launch_copyToPixel(hipStream_t s, void* pixel, const void* acu, float m, ui
 void launch_numerics(hipStream_t s, int op, const void* a, const void* b, void* out, uint64_t n) {
     if (!n) return;
     hipLaunchKernelGGL(k_numerics, grid1(n), dim3(256), 0, s, op, (const float*)a, (const float*)b, (float*)out, n);
+}
+void launch_divCheck(hipStream_t s, int mode, uint64_t seed, uint64_t count, void* out16) {
+    hipLaunchKernelGGL(k_divCheck, dim3(256 * 32), dim3(256), 0, s, mode, seed, count, (unsigned long long*)out16);
 }
 void launch_seedFill(hipStream_t s, void* seeds, uint64_t first, uint64_t count, uint32_t base) {
     if (!count) return;

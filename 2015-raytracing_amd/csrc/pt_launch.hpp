@@ -26,6 +26,7 @@ void launch_sceneRender(hipStream_t s, void* acu, void* pois, const void* shadow
                         const float* light, uint32_t total, uint32_t gsz);
 void launch_copyToPixel(hipStream_t s, void* pixel, const void* acu, float m, uint32_t pixels, uint32_t rpp, uint32_t gsz, void* radiance);
 void launch_numerics(hipStream_t s, int op, const void* a, const void* b, void* out, uint64_t n);
+void launch_divCheck(hipStream_t s, int mode, uint64_t seed, uint64_t count, void* out16);
 void launch_seedFill(hipStream_t s, void* seeds, uint64_t first, uint64_t count, uint32_t base);
 
 // ---- fused pass (pt_kernels_fused.hip) -------------------------------------------------------
@@ -41,6 +42,7 @@ struct GridArgs {            // one cell-sorted primitive set, device pointers
     uint32_t n;              // cells per axis
     uint32_t mesh_matid;
     uint32_t kind;           // KIND_SPHERES | KIND_TRIANGLES
+    uint32_t bounds_sane;    // every bound is 0 or has magnitude in [2^-30, 2^20] (host-checked): enables the shared-reciprocal AABB
     uint32_t exit_is_far_face; // n == 1 only: lo + 1*((hi-lo)/1) == hi and lo + 0*((hi-lo)/1) == lo hold bitwise on all three
                              // axes (checked on the host), so the single cell's exit t equals the AABB slab's far t
 };

@@ -16,6 +16,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef PT_EXACT_FAST_DIV
+#define PT_EXACT_FAST_DIV 0   // 1: shared-reciprocal / refined-reciprocal forms below (exact, validated on the device, but
+                              // slower in k_fusedPass today: -9 % VALU ops, +25 % SALU/SMEM and doubled s_waitcnt stalls from
+                              // the extra live registers -- DESIGN.md section 8); 0: the compiler's 11-op expansion everywhere
+#endif
+#ifndef PT_EXACT_FAST_TRI
+#define PT_EXACT_FAST_TRI 1   // the triangle determinant's reciprocal inside the primitive loops
+#endif
+#ifndef PT_EXACT_FAST_NORM
+#define PT_EXACT_FAST_NORM 1  // normalize() and the sphere's 1/(2a)
+#endif
+
 namespace pt {
 
 #define PT_DEV __device__ __forceinline__
@@ -42,6 +54,46 @@ PT_DEV uint32_t f2u(float f) {
     if (f >= 4294967296.0f) return UINT32_MAX;
     if (f <= 0.0f) return 0u;
     return (uint32_t)f;
+}
+
+// ---- exact division, cheaper ------------------------------------------------------------------------
+// hipcc expands a correctly rounded x/y into v_div_scale x2, v_rcp, 2 fma (reciprocal refinement), mul, 4 fma
+// (two quotient refinements, the last one v_div_fmas), v_div_fixup: 11 VALU ops, every time.  Two facts, both
+// established ON THE DEVICE against that expansion (mirt_debug_divcheck / profiles/divcheck.py,
+// tests/test_gpu_numerics.py), let the hot loops spend 3:
+//  (1) rcp_refined(d) = fma(fma(-d, r0, 1), r0, r0), r0 = v_rcp_f32(d), equals 1.0f/d for EVERY float d except
+//      +-0, +-inf, denormals and |d| >= 2^126 (checked over all 2^32 bit patterns; NaN gives NaN).
+//  (2) with r = rcp_refined(d): q0 = n*r, q = fma(fma(-d, q0, n), r, q0) equals n/d for |d| in [2^-40, 2^40],
+//      |n| in [2^-60, 2^60] (2^38 random pairs + every mantissa of d, zero mismatches); for n = +-0 the un-refined
+//      product n*r already is the quotient (sign included) and is what div_exact3 returns.
+// Outside those windows the affected lanes (and only they) redo the operation with the compiler's division.
+PT_DEV float rcp_refined(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+PT_DEV float div_shared(float n, float d, float r) {   // the compiler's five quotient operations, for the diagnostic
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+PT_DEV float div_exact3(float n, float d, float r) {
+    float q0 = n * r;
+    float q = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0);
+    return (n == 0.0f) ? q0 : q;
+}
+PT_DEV bool rcp_window(float x) { return __builtin_fabsf(x) >= 1.17549435e-38f && __builtin_fabsf(x) < 8.5070592e37f; }   // normal, < 2^126
+// 1.0f/x, bit for bit.  `dont_care`: lanes whose result is never used (they must not force the slow path).
+PT_DEV float rcp_exact(float x, bool dont_care = false) {
+#if PT_EXACT_FAST_DIV && PT_EXACT_FAST_NORM
+    float r = rcp_refined(x);
+    if (__builtin_expect(!(dont_care || rcp_window(x)), 0)) r = 1.0f / x;   // rare lanes only: s_cbranch_execz skips it
+    return r;
+#else
+    return 1.0f / x;
+#endif
 }
 
 // sin and cos of one angle.  k = rint(x*2/pi) by the 1.5*2^23 trick; r = x - k*pi/2 in

@@ -78,6 +78,7 @@ SYMBOLS = {
     "mirt_timer_stop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mirt_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mirt_pass_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mirt_debug_divcheck": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "mirt_debug_numerics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
@@ -243,6 +244,13 @@ class Context:
             if x:
                 x.release()
         return out
+
+    def divcheck(self, mode, seed, count):
+        out = self.buffer(16 * 8)
+        self._chk(lib().mirt_debug_divcheck(self.h, mode, seed, count, out.h))
+        r = out.read(np.uint64, 16)
+        out.release()
+        return r
 
     def render_pass(self, desc):
         self._chk(lib().mirt_render_pass(self.h, C.byref(desc)))

@@ -37,6 +37,9 @@ BYTES_PER_SAMPLE_FUSED = 40.0       # seed 4 in + 4 out, accumulator 16 in + 16 
 BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0
 PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA-counted)
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r1d_park_lds: FETCH_SIZE x 2 + WRITE_SIZE,
+# KiB -> bytes; gfx950 halves FETCH_SIZE on wide coalesced reads, MI355X_MICROARCH.md).  Valid for the default workload only.
+TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 14.79e9, "write_bytes": 55.27e9, "source": "profiles/r1d_park_lds/pmc_summary.json"}
 
 
 def cpu_baseline(packed_json, log):
@@ -157,6 +160,8 @@ def main():
     valu_tf = flops * local_samples / (fused_ms * 1e-3) / 1e12
     hbm_gbs = BYTES_PER_SAMPLE_FUSED * local_samples / (fused_ms * 1e-3) / 1e9
 
+    default_wl = (world == 1 and (sc.width, sc.height, sc.rpp, args.bounces) == (1920, 1080, 256, 5))
+    traffic = (TRAFFIC_DEFAULT_WORKLOAD["fetch_bytes"] + TRAFFIC_DEFAULT_WORKLOAD["write_bytes"]) if default_wl else None
     out = {
         "metric": "Msamples/sec (pixels x spp) at 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -168,10 +173,11 @@ def main():
                    "width": sc.width, "height": sc.height, "rays_per_pixel": sc.rpp, "bounces": args.bounces,
                    "parallelism": f"rows/{world}"},
         "roofline": {"kernel": "pt::k_fusedPass", "bound": "valu", "achieved": round(valu_tf, 2), "peak": PEAK_VALU_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(valu_tf / PEAK_VALU_TFLOPS, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(valu_tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic,
                      "flops_per_sample": flops, "launch_ms": round(fused_ms, 3), "resolve_ms": round(resolve_ms, 3)},
         "roofline_hbm": {"kernel": "pt::k_fusedPass", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
-                         "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
+                         "traffic_note": "algorithmic 21.2 GB/launch; the excess is register-spill scratch (56 B/lane) written back through L2",
                          "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

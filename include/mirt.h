@@ -176,6 +176,10 @@ MIRT_API int mirt_zero(mirt_ctx* ctx, mirt_buf* buf);
  * Lets a test compare device bits with host bits over millions of inputs. ---------------- */
 MIRT_API int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n);
 
+/* counts mismatches between the shared-reciprocal division forms of pt_numerics.hpp and the compiler's correctly
+ * rounded division over `count` generated (n, d) pairs; `out16` receives 16 uint64 (see k_divCheck) */
+MIRT_API int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16);
+
 /* ---- measurement: HIP events on the context's stream ---------------------------------- */
 MIRT_API int mirt_timer_start(mirt_ctx* ctx);
 MIRT_API int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms);   /* synchronises */

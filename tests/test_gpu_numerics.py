@@ -103,3 +103,17 @@ def test_concentric_map_matches_cpu_formula(ctx):
     x, y = ctx.debug_numerics(11, u, v), ctx.debug_numerics(12, u, v)
     assert (x * x + y * y <= 1.0 + 1e-6).all()
     # exact comparison against the CPU pipeline happens in test_gpu_parity (every ray goes through it)
+
+
+def test_cheap_exact_division_forms(ctx):
+    """The 3-operation reciprocal and shared-reciprocal quotient the hot loops use (pt_numerics.hpp) against the
+    compiler's 11-operation correctly rounded division, on the device."""
+    r = ctx.divcheck(3, 0, 1 << 32)
+    # every bit pattern: the only denominators where rcp_refined != 1/d are +-0, +-inf, denormals and |d| > 2^126
+    assert int(r[1]) == 3 * 2**24      # 2 zeros + 2 infs + 2(2^23 - 1) denormals + 2(2^24 - 1) patterns with |d| > 2^126
+    for mode, count in ((0, 1 << 31), (1, 81 << 23), (2, 1 << 33)):
+        r = ctx.divcheck(mode, 4242 + mode, count)
+        assert int(r[12]) == 0, f"div_exact3 differs from n/d on {int(r[12])} of {count} pairs (mode {mode})"
+        assert int(r[1]) == 0 and int(r[2]) == 0
+        if mode == 2:
+            assert int(r[0]) == 0 and int(r[3]) == 0       # without +-0 numerators even the bare forms agree
