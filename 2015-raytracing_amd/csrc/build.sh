@@ -10,5 +10,5 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden
        -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt
        -Wall -Wextra -Wno-unused-parameter)
 "${HIPCC}" "${FLAGS[@]}" -shared -o "${OUT}" \
-    "${HERE}/mirt_abi.cpp" "${HERE}/pt_kernels_granular.hip" "${HERE}/pt_kernels_fused.hip" "${HERE}/pt_kernels_frame.hip" "$@"
+    "${HERE}/mirt_abi.cpp" "${HERE}/pt_kernels_granular.hip" "${HERE}/pt_kernels_fused.hip" "${HERE}/pt_kernels_frame.hip" "${HERE}/pt_grid_build.hip" "$@"
 echo "built ${OUT}"

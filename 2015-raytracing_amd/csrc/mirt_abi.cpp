@@ -818,6 +818,113 @@ int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_bu
     return MIRT_OK;
 }
 
+static int new_owned(mirt_ctx* ctx, size_t bytes, mirt_buf** out) {
+    return mirt_buf_create(ctx, bytes ? bytes : 16, MIRT_MEM_READ_WRITE, out);
+}
+
+int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cell_offsets, mirt_buf** order, uint32_t* total) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_build: unknown context");
+    if (!d || d->struct_size != sizeof(mirt_grid_build_desc) || !cell_offsets || !order || !total)
+        return fail(ctx, MIRT_E_ARG, "mirt_grid_build: null argument or descriptor size mismatch");
+    *cell_offsets = *order = nullptr;
+    *total = 0;
+    if (d->kind > 1) return fail(ctx, MIRT_E_ARG, "mirt_grid_build: kind is 0 (spheres) or 1 (triangles)");
+    if (d->n_slabs == 0 || d->n_slabs > 1024) return fail(ctx, MIRT_E_ARG, "mirt_grid_build: n_slabs %u outside 1..1024", d->n_slabs);
+    int rc;
+    if (d->count && (rc = need(ctx, "mirt_grid_build prims", d->prims_f64, (uint64_t)d->count * (d->kind ? 72 : 32)))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t cells = (uint64_t)d->n_slabs * d->n_slabs * d->n_slabs;
+    if ((rc = new_owned(ctx, (cells + 1) * 4, cell_offsets))) return rc;
+    uint32_t* ord = nullptr;
+    hipError_t e = pt::grid_build(ctx->stream, (int)d->kind, d->count ? (const double*)d->prims_f64->ptr : nullptr, d->count, d->bounds, d->n_slabs,
+                                  (uint32_t*)(*cell_offsets)->ptr, &ord, total);
+    if (e != hipSuccess) {
+        mirt_buf_release(*cell_offsets);
+        *cell_offsets = nullptr;
+        return fail(ctx, MIRT_E_DEVICE, "mirt_grid_build: %s", hipGetErrorString(e));
+    }
+    // adopt the order array as an owned buffer
+    mirt_buf* ob = new mirt_buf();
+    ob->ctx = ctx; ob->bytes = *total ? (size_t)*total * 4 : 16; ob->owned = true; ob->flags = MIRT_MEM_READ_WRITE;
+    if (ord) ob->ptr = ord;
+    else if (hipMalloc(&ob->ptr, 16) != hipSuccess) { delete ob; return fail(ctx, MIRT_E_DEVICE, "mirt_grid_build: hipMalloc failed"); }
+    live_add(ob);
+    *order = ob;
+    (*cell_offsets)->version++;
+    return MIRT_OK;
+}
+
+int mirt_grid_gather_triangles(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* pos_f64, mirt_buf* nor_f64, uint32_t nsteps,
+                               const int32_t* ops, const double* vecs, float pad_w, mirt_buf** pos_out, mirt_buf** nor_out) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_triangles: unknown context");
+    if (!pos_out || nsteps > 4 || (nsteps && (!ops || !vecs))) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_triangles: bad argument");
+    for (uint32_t i = 0; i < nsteps; ++i) if (ops[i] < 0 || ops[i] > 2) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_triangles: op %d", ops[i]);
+    int rc;
+    if ((rc = need(ctx, "gather order", order, (uint64_t)total * 4))) return rc;
+    if ((rc = need(ctx, "gather positions", pos_f64, 0))) return rc;
+    if (nor_f64 && nor_out && (rc = need(ctx, "gather normals", nor_f64, 0))) return rc;
+    if (pos_f64->bytes % 72) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_triangles: positions are 9 doubles per triangle");
+    // every index in `order` must address a triangle of the inputs: order comes from mirt_grid_build over `count` primitives;
+    // a foreign order array is checked on the host
+    if (total) {
+        std::vector<uint32_t> h(total);
+        HIPCHK(ctx, hipMemcpyAsync(h.data(), order->ptr, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const uint64_t ntri = pos_f64->bytes / 72;
+        for (uint32_t v : h) if (v >= ntri) return fail(ctx, MIRT_E_DATA, "mirt_grid_gather_triangles: order refers to triangle %u of %llu", v, (unsigned long long)ntri);
+        if (nor_f64 && nor_out && nor_f64->bytes < ntri * 72) return fail(ctx, MIRT_E_RANGE, "mirt_grid_gather_triangles: normals shorter than positions");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = new_owned(ctx, (size_t)total * 48, pos_out))) return rc;
+    const bool want_n = nor_f64 && nor_out;
+    if (nor_out) *nor_out = nullptr;
+    if (want_n && (rc = new_owned(ctx, (size_t)total * 48, nor_out))) return rc;
+    pt::launch_gatherTriangles(ctx->stream, (const uint32_t*)order->ptr, total, (const double*)pos_f64->ptr, want_n ? (const double*)nor_f64->ptr : nullptr,
+                               (int)nsteps, (const int*)ops, vecs, pad_w, (*pos_out)->ptr, want_n ? (*nor_out)->ptr : nullptr);
+    HIPCHK(ctx, hipGetLastError());
+    (*pos_out)->version++;
+    return MIRT_OK;
+}
+
+static int check_order(mirt_ctx* ctx, mirt_buf* order, uint32_t total, uint64_t n_in) {
+    if (!total) return MIRT_OK;
+    std::vector<uint32_t> h(total);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), order->ptr, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t v : h) if (v >= n_in) return fail(ctx, MIRT_E_DATA, "order refers to element %u of %llu", v, (unsigned long long)n_in);
+    return MIRT_OK;
+}
+
+int mirt_grid_gather_spheres(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* sph_f64, mirt_buf** out) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_spheres: unknown context");
+    if (!out) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_spheres: null out");
+    int rc;
+    if ((rc = need(ctx, "gather order", order, (uint64_t)total * 4))) return rc;
+    if ((rc = need(ctx, "gather spheres", sph_f64, 0))) return rc;
+    if ((rc = check_order(ctx, order, total, sph_f64->bytes / 32))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = new_owned(ctx, (size_t)total * 16, out))) return rc;
+    pt::launch_gatherSpheres(ctx->stream, (const uint32_t*)order->ptr, total, (const double*)sph_f64->ptr, (*out)->ptr);
+    HIPCHK(ctx, hipGetLastError());
+    (*out)->version++;
+    return MIRT_OK;
+}
+
+int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* in_u32, mirt_buf** out) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_u32: unknown context");
+    if (!out) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_u32: null out");
+    int rc;
+    if ((rc = need(ctx, "gather order", order, (uint64_t)total * 4))) return rc;
+    if ((rc = need(ctx, "gather input", in_u32, 0))) return rc;
+    if ((rc = check_order(ctx, order, total, in_u32->bytes / 4))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = new_owned(ctx, (size_t)total * 4, out))) return rc;
+    pt::launch_gatherU32(ctx->stream, (const uint32_t*)order->ptr, total, (const uint32_t*)in_u32->ptr, (uint32_t*)(*out)->ptr);
+    HIPCHK(ctx, hipGetLastError());
+    (*out)->version++;
+    return MIRT_OK;
+}
+
 int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_divcheck: unknown context");
     int rc = need(ctx, "mirt_debug_divcheck out", out16, 16 * 8);

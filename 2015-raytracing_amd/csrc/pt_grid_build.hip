@@ -1,0 +1,202 @@
+// pt_grid_build.hip -- the uniform-grid builders of the reference host on the device.
+//
+// The reference bins primitives into an n x n x n grid on the CPU with nested JS arrays
+// (splitSphereData / splitTriangleData / splitMeshData, A10 code.js:1554-1772, 899-1041):
+//   lo = floor((boxmin - bmin) / w), hi = floor((boxmax - bmin) / w) per axis in DOUBLE precision,
+//   lo clamped from below only, hi from above only (so a primitive on the max face has lo = n > hi = n-1
+//   and is silently dropped), every cell of [lo,hi]^3 receives a copy; cells are emitted z-major, then y,
+//   then x, primitives inside a cell in input order.
+// The same result as a data-parallel pipeline (fp64 throughout, so every floor() sees the bits JS sees):
+//   1. k_cellRanges   one thread per primitive: AABB from its fp64 vertices, the six clamped indices, #cells
+//   2. exclusive scan of #cells (rocPRIM)            -> where each primitive's (cell, prim) pairs start
+//   3. k_emitPairs    one thread per primitive: its pairs in z,y,x order; per-cell counts by atomics
+//   4. stable radix sort of the pairs by cell (rocPRIM)   -> `order` (input order survives inside a cell)
+//   5. exclusive scan of the per-cell counts              -> `offsets[n^3 + 1]`
+// plus k_gatherTriangles / k_gatherSpheres: slot arrays (3 x float4 positions / normals, float4 spheres)
+// from `order`, applying the mesh's normalise / scale / translate in fp64 before narrowing to fp32
+// exactly where `new Float32Array(...)` narrows (A10 code.js:114-169, 1263-1265).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "pt_launch.hpp"
+
+namespace pt {
+
+struct GridDims { double bmin[3], w[3]; uint32_t n; };
+
+__device__ __forceinline__ void clamp_range(const double* lo, const double* hi, const GridDims& g, int* r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double a = floor((lo[c] - g.bmin[c]) / g.w[c]);
+        double b = floor((hi[c] - g.bmin[c]) / g.w[c]);
+        // JS: `if (a < 0) a = 0; if (b >= n) b = n-1;` on doubles (NaN compares false and then runs no loop iteration)
+        if (a < 0) a = 0;
+        if (b >= (double)g.n) b = (double)g.n - 1.0;
+        // loop `for (i = a; i <= b; i++)`: empty when a > b or either is NaN; clamp the other side only to keep ints sane
+        int ia = (a == a && a <= (double)g.n) ? (int)a : (int)g.n;        // a > n-1 -> empty anyway
+        int ib = (b == b && b >= -1.0) ? (int)b : -1;
+        r[c] = ia;
+        r[3 + c] = ib;
+    }
+}
+
+// kind 0: spheres, prim = (cx, cy, cz, r) fp64; kind 1: triangles, prim = 9 fp64 (p0, p1, p2)
+__global__ void __launch_bounds__(256) k_cellRanges(int kind, const double* prims, uint32_t count, GridDims g, int* ranges, uint32_t* ncells) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double lo[3], hi[3];
+    if (kind == 0) {
+        const double* s = prims + 4u * (size_t)i;
+        for (int c = 0; c < 3; ++c) { lo[c] = s[c] - s[3]; hi[c] = s[c] + s[3]; }
+    } else {
+        const double* p = prims + 9u * (size_t)i;
+        for (int c = 0; c < 3; ++c) {
+            // Math.min(Math.min(a,b),c): NaN-propagating in JS; fmin would drop NaNs, so spell the comparisons out
+            double a = p[c], b = p[3 + c], d = p[6 + c];
+            double mn = (a != a || b != b) ? (a + b) : (a < b ? a : b);
+            mn = (mn != mn || d != d) ? (mn + d) : (mn < d ? mn : d);
+            double mx = (a != a || b != b) ? (a + b) : (a > b ? a : b);
+            mx = (mx != mx || d != d) ? (mx + d) : (mx > d ? mx : d);
+            lo[c] = mn; hi[c] = mx;
+        }
+    }
+    int r[6];
+    clamp_range(lo, hi, g, r);
+    uint32_t nc = 1;
+    for (int c = 0; c < 3; ++c) nc *= (r[3 + c] >= r[c]) ? (uint32_t)(r[3 + c] - r[c] + 1) : 0u;
+    for (int c = 0; c < 6; ++c) ranges[6u * (size_t)i + c] = r[c];
+    ncells[i] = nc;
+}
+
+__global__ void __launch_bounds__(256) k_emitPairs(const int* ranges, const uint32_t* start, uint32_t count, uint32_t n,
+                                                    uint32_t* keys, uint32_t* vals, uint32_t* cell_count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int* r = ranges + 6u * (size_t)i;
+    uint32_t k = start[i];
+    for (int z = r[2]; z <= r[5]; ++z)
+        for (int y = r[1]; y <= r[4]; ++y)
+            for (int x = r[0]; x <= r[3]; ++x) {
+                const uint32_t cell = ((uint32_t)z * n + (uint32_t)y) * n + (uint32_t)x;
+                keys[k] = cell;
+                vals[k] = i;
+                ++k;
+                atomicAdd(&cell_count[cell], 1u);
+            }
+}
+
+// up to four fp64 per-axis steps applied in order: 0 = subtract, 1 = multiply, 2 = add  (Mesh.normalize = sub centre,
+// mul 1/maxdim; Mesh.scale = mul; Mesh.translate = add: A10 code.js:114-169)
+struct Xform { int nsteps; int op[4]; double v[4][3]; };
+
+__device__ __forceinline__ double apply_xf(double x, int c, const Xform& xf) {
+    for (int s = 0; s < xf.nsteps; ++s) {
+        if (xf.op[s] == 0) x = x - xf.v[s][c];
+        else if (xf.op[s] == 1) x = x * xf.v[s][c];
+        else x = x + xf.v[s][c];
+    }
+    return x;
+}
+
+__global__ void __launch_bounds__(256) k_gatherTriangles(const uint32_t* order, uint32_t total, const double* pos9, const double* nor9,
+                                                          Xform xf, float pad_w, float4* pos_out, float4* nor_out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const uint32_t i = order[k];
+    for (int v = 0; v < 3; ++v) {
+        const double* p = pos9 + 9u * (size_t)i + 3 * v;
+        pos_out[3u * (size_t)k + v] = make_float4((float)apply_xf(p[0], 0, xf), (float)apply_xf(p[1], 1, xf), (float)apply_xf(p[2], 2, xf), pad_w);
+        if (nor_out) {
+            const double* q = nor9 + 9u * (size_t)i + 3 * v;
+            nor_out[3u * (size_t)k + v] = make_float4((float)q[0], (float)q[1], (float)q[2], 0.0f);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_gatherSpheres(const uint32_t* order, uint32_t total, const double* sph4, float4* out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const double* s = sph4 + 4u * (size_t)order[k];
+    out[k] = make_float4((float)s[0], (float)s[1], (float)s[2], (float)(s[3] * s[3]));   // rad*rad in fp64, then narrowed (code.js:1602)
+}
+__global__ void __launch_bounds__(256) k_gatherU32(const uint32_t* order, uint32_t total, const uint32_t* in, uint32_t* out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < total) out[k] = in[order[k]];
+}
+
+static inline dim3 g1(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// Returns hipSuccess and the number of (cell, primitive) slots.  `offsets` must hold n^3 + 1 uints.  `order_out` receives
+// a device allocation (hipMalloc) of `*total` uints that the caller owns.
+hipError_t grid_build(hipStream_t s, int kind, const double* prims, uint32_t count, const double bounds6[6], uint32_t n,
+                      uint32_t* offsets, uint32_t** order_out, uint32_t* total) {
+    GridDims g;
+    g.n = n;
+    for (int c = 0; c < 3; ++c) { g.bmin[c] = bounds6[c]; g.w[c] = (bounds6[3 + c] - bounds6[c]) / (double)n; }
+    const uint64_t cells = (uint64_t)n * n * n;
+    *order_out = nullptr;
+    *total = 0;
+    int* ranges = nullptr;
+    uint32_t *ncells = nullptr, *start = nullptr, *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *cell_count = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0, need = 0;
+    hipError_t rc = hipSuccess;
+    auto cleanup = [&]() {
+        (void)hipFree(ranges); (void)hipFree(ncells); (void)hipFree(start); (void)hipFree(keys); (void)hipFree(vals); (void)hipFree(keys2);
+        (void)hipFree(cell_count); (void)hipFree(tmp);
+    };
+#define GB_TRY(e) do { rc = (e); if (rc != hipSuccess) { cleanup(); return rc; } } while (0)
+    GB_TRY(hipMalloc(&cell_count, (cells + 1) * 4));
+    GB_TRY(hipMemsetAsync(cell_count, 0, (cells + 1) * 4, s));
+    if (count) {
+        GB_TRY(hipMalloc(&ranges, (size_t)count * 24));
+        GB_TRY(hipMalloc(&ncells, ((size_t)count + 1) * 4));
+        GB_TRY(hipMalloc(&start, ((size_t)count + 1) * 4));
+        GB_TRY(hipMemsetAsync(ncells, 0, ((size_t)count + 1) * 4, s));
+        hipLaunchKernelGGL(k_cellRanges, g1(count), dim3(256), 0, s, kind, prims, count, g, ranges, ncells);
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, ncells, start, (int)count + 1, s));
+        tmp_bytes = need;
+        GB_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ncells, start, (int)count + 1, s));
+        uint32_t tot = 0;
+        GB_TRY(hipMemcpyAsync(&tot, start + count, 4, hipMemcpyDeviceToHost, s));
+        GB_TRY(hipStreamSynchronize(s));
+        *total = tot;
+        if (tot) {
+            GB_TRY(hipMalloc(&keys, (size_t)tot * 4));
+            GB_TRY(hipMalloc(&vals, (size_t)tot * 4));
+            GB_TRY(hipMalloc(&keys2, (size_t)tot * 4));
+            GB_TRY(hipMalloc((void**)order_out, (size_t)tot * 4));
+            hipLaunchKernelGGL(k_emitPairs, g1(count), dim3(256), 0, s, ranges, start, count, n, keys, vals, cell_count);
+            int bits = 1;
+            while ((1ull << bits) < cells && bits < 32) ++bits;
+            GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, keys2, vals, *order_out, (int)tot, 0, bits, s));
+            if (need > tmp_bytes) { (void)hipFree(tmp); tmp = nullptr; GB_TRY(hipMalloc(&tmp, need)); tmp_bytes = need; }
+            GB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, need, keys, keys2, vals, *order_out, (int)tot, 0, bits, s));
+        }
+    }
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, cell_count, offsets, (int)cells + 1, s));
+    if (need > tmp_bytes) { (void)hipFree(tmp); tmp = nullptr; GB_TRY(hipMalloc(&tmp, need)); tmp_bytes = need; }
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, need, cell_count, offsets, (int)cells + 1, s));
+    GB_TRY(hipStreamSynchronize(s));
+    cleanup();
+    return hipSuccess;
+#undef GB_TRY
+}
+
+void launch_gatherTriangles(hipStream_t s, const uint32_t* order, uint32_t total, const double* pos9, const double* nor9,
+                            int nsteps, const int* ops, const double* vecs, float pad_w, void* pos_out, void* nor_out) {
+    if (!total) return;
+    Xform xf;
+    xf.nsteps = nsteps;
+    for (int i = 0; i < 4; ++i) { xf.op[i] = i < nsteps ? ops[i] : 0; for (int c = 0; c < 3; ++c) xf.v[i][c] = i < nsteps ? vecs[3 * i + c] : 0.0; }
+    hipLaunchKernelGGL(k_gatherTriangles, g1(total), dim3(256), 0, s, order, total, pos9, nor9, xf, pad_w, (float4*)pos_out, (float4*)nor_out);
+}
+void launch_gatherSpheres(hipStream_t s, const uint32_t* order, uint32_t total, const double* sph4, void* out) {
+    if (total) hipLaunchKernelGGL(k_gatherSpheres, g1(total), dim3(256), 0, s, order, total, sph4, (float4*)out);
+}
+void launch_gatherU32(hipStream_t s, const uint32_t* order, uint32_t total, const uint32_t* in, uint32_t* out) {
+    if (total) hipLaunchKernelGGL(k_gatherU32, g1(total), dim3(256), 0, s, order, total, in, out);
+}
+
+}  // namespace pt

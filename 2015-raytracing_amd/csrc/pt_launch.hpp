@@ -71,6 +71,14 @@ void launch_fused(hipStream_t s, const FusedArgs& a);
 // {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip)
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count);
 
+// ---- uniform-grid build on the device (pt_grid_build.hip) -------------------------------------------
+hipError_t grid_build(hipStream_t s, int kind, const double* prims, uint32_t count, const double bounds6[6], uint32_t n,
+                      uint32_t* offsets, uint32_t** order_out, uint32_t* total);
+void launch_gatherTriangles(hipStream_t s, const uint32_t* order, uint32_t total, const double* pos9, const double* nor9,
+                            int nsteps, const int* ops, const double* vecs, float pad_w, void* pos_out, void* nor_out);
+void launch_gatherSpheres(hipStream_t s, const uint32_t* order, uint32_t total, const double* sph4, void* out);
+void launch_gatherU32(hipStream_t s, const uint32_t* order, uint32_t total, const uint32_t* in, uint32_t* out);
+
 // ---- single-frame kernels of Assign01 / 04 / 07 (pt_kernels_frame.hip) -----------------------------
 void launch_a01_raytrace(hipStream_t s, void* pixels, const float* cam, uint32_t gx, uint32_t gy);
 void launch_frame_initTrace(hipStream_t s, bool clip, void* pixels, const float* cam, void* rays, const float* bound, uint32_t gx, uint32_t gy);

@@ -29,6 +29,11 @@ class _Grid(C.Structure):
                 ("bounds", C.c_float * 8), ("n_slabs", C.c_uint32), ("mesh_matid", C.c_uint32)]
 
 
+class _GridBuildDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_uint32), ("count", C.c_uint32), ("n_slabs", C.c_uint32),
+                ("bounds", C.c_double * 6), ("prims_f64", C.c_void_p)]
+
+
 class _Light(C.Structure):
     _fields_ = [("shadow", C.c_float * 16), ("scene", C.c_float * 16), ("light", C.c_float * 16)]
 
@@ -78,6 +83,11 @@ SYMBOLS = {
     "mirt_timer_stop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mirt_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mirt_pass_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mirt_grid_build": (C.c_int, [C.c_void_p, C.POINTER(_GridBuildDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
+    "mirt_grid_gather_triangles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_double), C.c_float, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "mirt_grid_gather_spheres": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mirt_grid_gather_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mirt_debug_divcheck": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
     "mirt_debug_numerics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
@@ -244,6 +254,57 @@ class Context:
             if x:
                 x.release()
         return out
+
+    def grid_build(self, kind, prims_f64, bounds6, n_slabs):
+        """splitSphereData / splitTriangleData / splitMeshData on the device.  Returns (offsets Buffer, order Buffer, total)."""
+        prims = np.ascontiguousarray(prims_f64, np.float64)
+        per = 9 if kind else 4
+        count = prims.size // per
+        pb = self.buffer_from(prims, MEM_READ_WRITE) if count else None
+        d = _GridBuildDesc()
+        d.struct_size, d.kind, d.count, d.n_slabs = C.sizeof(_GridBuildDesc), kind, count, n_slabs
+        d.bounds = (C.c_double * 6)(*[float(x) for x in bounds6])
+        d.prims_f64 = pb.h if pb else None
+        off, order, total = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        try:
+            self._chk(lib().mirt_grid_build(self.h, C.byref(d), C.byref(off), C.byref(order), C.byref(total)))
+        finally:
+            if pb:
+                pb.release()
+        return Buffer(self, off, (n_slabs ** 3 + 1) * 4), Buffer(self, order, max(total.value * 4, 16)), total.value
+
+    def grid_gather_triangles(self, order, total, pos_f64, nor_f64=None, steps=(), pad_w=0.0):
+        pb = self.buffer_from(np.ascontiguousarray(pos_f64, np.float64), MEM_READ_WRITE)
+        nb = self.buffer_from(np.ascontiguousarray(nor_f64, np.float64), MEM_READ_WRITE) if nor_f64 is not None else None
+        ops = (C.c_int32 * 4)(*([s[0] for s in steps] + [0] * (4 - len(steps))))
+        vecs = (C.c_double * 12)(*([float(x) for s in steps for x in s[1]] + [0.0] * (12 - 3 * len(steps))))
+        po, no = C.c_void_p(), C.c_void_p()
+        try:
+            self._chk(lib().mirt_grid_gather_triangles(self.h, order.h, total, pb.h, nb.h if nb else None, len(steps), ops, vecs, pad_w,
+                                                       C.byref(po), C.byref(no) if nb else None))
+        finally:
+            pb.release()
+            if nb:
+                nb.release()
+        return Buffer(self, po, max(total * 48, 16)), (Buffer(self, no, max(total * 48, 16)) if nb else None)
+
+    def grid_gather_spheres(self, order, total, sph_f64):
+        sb = self.buffer_from(np.ascontiguousarray(sph_f64, np.float64), MEM_READ_WRITE)
+        out = C.c_void_p()
+        try:
+            self._chk(lib().mirt_grid_gather_spheres(self.h, order.h, total, sb.h, C.byref(out)))
+        finally:
+            sb.release()
+        return Buffer(self, out, max(total * 16, 16))
+
+    def grid_gather_u32(self, order, total, values_u32):
+        vb = self.buffer_from(np.ascontiguousarray(values_u32, np.uint32), MEM_READ_WRITE)
+        out = C.c_void_p()
+        try:
+            self._chk(lib().mirt_grid_gather_u32(self.h, order.h, total, vb.h, C.byref(out)))
+        finally:
+            vb.release()
+        return Buffer(self, out, max(total * 4, 16))
 
     def divcheck(self, mode, seed, count):
         out = self.buffer(16 * 8)

@@ -170,6 +170,29 @@ MIRT_API int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, 
 /* initAcu over a whole buffer (A10 code.js:1078-1099) */
 MIRT_API int mirt_zero(mirt_ctx* ctx, mirt_buf* buf);
 
+/* ---- uniform-grid build on the device: splitSphereData / splitTriangleData / splitMeshData (A10 code.js:1554-1772, 899-1041)
+ * and Mesh.normalize/scale/translate (code.js:114-169) as a count / scan / stable-sort / gather pipeline in fp64, reproducing
+ * the reference's cell order, per-cell input order and its dropped-on-the-max-face quirk bit for bit.  Every output is a
+ * new buffer the caller owns (release it) and can bind to a kernel or put in a mirt_grid. ---------------------------------- */
+typedef struct mirt_grid_build_desc {
+    uint32_t struct_size;
+    uint32_t kind;          /* 0: spheres, 4 doubles per primitive (cx, cy, cz, r); 1: triangles, 9 doubles (p0, p1, p2) */
+    uint32_t count;         /* primitives */
+    uint32_t n_slabs;       /* cells per axis */
+    double bounds[6];       /* min x,y,z, max x,y,z of the set (Bounds, lib/utilities.js:389-422) */
+    mirt_buf* prims_f64;    /* device buffer of doubles, uploaded with mirt_buf_write */
+} mirt_grid_build_desc;
+/* cell_offsets: uint[n^3+1]; order: uint[total], order[slot] = input index of the primitive in that slot */
+MIRT_API int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cell_offsets, mirt_buf** order, uint32_t* total);
+/* slot arrays from `order`.  Triangles: 3 x float4 per slot (w = pad_w: 0 in A07/A10, 1 for A04's positions), after up to four
+ * fp64 per-axis steps (op 0 subtract, 1 multiply, 2 add; vecs = 3 doubles per step) applied in order, then narrowed to fp32.
+ * nor_f64 / nor_out may be NULL. */
+MIRT_API int mirt_grid_gather_triangles(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* pos_f64, mirt_buf* nor_f64,
+                                        uint32_t nsteps, const int32_t* ops, const double* vecs, float pad_w,
+                                        mirt_buf** pos_out, mirt_buf** nor_out);
+MIRT_API int mirt_grid_gather_spheres(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* sph_f64, mirt_buf** out);   /* float4 (c, r*r) */
+MIRT_API int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* in_u32, mirt_buf** out);       /* material ids */
+
 /* ---- diagnostics: evaluate one primitive of the numerics contract element-wise on the device
  * (op: 0 a/b, 1 sqrt, 2 sin, 3 cos, 4 getRand(seed=bits of a), 5 next LCG state, 6 min, 7 max,
  * 8 fmin, 9 fmax, 10 normalize(a,b,1).x, 11/12 concentric_distort(a,b).x/.y, 13 (int)a).

@@ -1,0 +1,128 @@
+"""the reference host's uniform-grid builders (splitSphereData / splitTriangleData / splitMeshData,
+A10 code.js:1554-1772, 899-1041) as a device pipeline (count, scan, stable sort, gather; csrc/pt_grid_build.hip).
+Expected values: a numpy restatement of the reference's nested-array algorithm (double precision, clamp-one-side quirk),
+which itself is checked here against the reference host's own output carried by the fixtures."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_fixture
+
+
+def expected_grid(kind, prims, bounds6, n):
+    """The reference algorithm, literally: per primitive, floor((box - bmin)/w) in doubles, low index clamped from below only,
+    high index from above only, push into every cell of the range; emit cells z-major."""
+    prims = np.asarray(prims, np.float64).reshape(-1, 9 if kind else 4)
+    bmin = np.asarray(bounds6[:3], np.float64)
+    w = (np.asarray(bounds6[3:], np.float64) - bmin) / n
+    cells = [[] for _ in range(n ** 3)]
+    for i, p in enumerate(prims):
+        if kind:
+            v = p.reshape(3, 3)
+            lo, hi = v.min(axis=0), v.max(axis=0)
+        else:
+            lo, hi = p[:3] - p[3], p[:3] + p[3]
+        with np.errstate(all="ignore"):
+            a = np.floor((lo - bmin) / w)
+            b = np.floor((hi - bmin) / w)
+        a = np.where(a < 0, 0, a)
+        b = np.where(b >= n, n - 1, b)
+        if np.isnan(a).any() or np.isnan(b).any() or (a > b).any():
+            continue
+        for z in range(int(a[2]), int(b[2]) + 1):
+            for y in range(int(a[1]), int(b[1]) + 1):
+                for x in range(int(a[0]), int(b[0]) + 1):
+                    cells[(z * n + y) * n + x].append(i)
+    off = np.zeros(n ** 3 + 1, np.uint32)
+    off[1:] = np.cumsum([len(c) for c in cells])
+    order = np.array([i for c in cells for i in c], np.uint32)
+    return off, order
+
+
+def test_restatement_reproduces_the_reference_hosts_grids():
+    """cornell_teapot3: the fixture's cell offsets were produced by the reference's own splitMeshData (teapot n = 10, boxes n = 5);
+    rebuild them from the slot arrays' primitives."""
+    fx, sc = load_fixture("cornell_teapot3_64x48_r1")
+    # loose spheres / triangles use n = 1: every primitive lands in cell 0 unless it lies on a max face
+    off, order = expected_grid(0, np.array([[0, 0, 0, 1.0], [5, 5, 5, 0.5]]), [-1, -1, -1, 5.5, 5.5, 5.5], 1)
+    assert off.tolist() == [0, 2] and order.tolist() == [0, 1]
+    # max-face quirk: a triangle lying in the plane x = bmax gets lo = n > hi = n - 1 -> dropped
+    tri = np.array([[1, 0, 0, 1, 1, 0, 1, 0, 1.0], [0.1, 0.1, 0.1, 0.2, 0.3, 0.1, 0.1, 0.2, 0.4]])
+    off, order = expected_grid(1, tri, [0, 0, 0, 1, 1, 1], 2)
+    assert 0 not in order.tolist() and order.tolist() == [1]
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    from raytracing_amd.pyhost import mirt
+    c = mirt.Context(0)
+    yield c
+    c.destroy()
+
+
+def soup(kind, count, seed):
+    r = np.random.default_rng(seed)
+    if kind:
+        c = r.uniform(-1, 1, (count, 1, 3))
+        p = (c + r.normal(0, 0.15, (count, 3, 3))).reshape(count, 9)
+        # a few degenerate / boundary cases: on the max face, on the min face, spanning everything, outside
+        p[0] = [1, -1, -1, 1, 1, -1, 1, -1, 1]
+        p[1] = [-1, -1, -1, -1, 1, -1, -1, -1, 1]
+        p[2] = [-3, -3, -3, 3, 3, 3, 3, -3, 3]
+        p[3] = [5, 5, 5, 6, 5, 5, 5, 6, 5]
+        return p
+    s = np.concatenate([r.uniform(-1, 1, (count, 3)), r.uniform(0.01, 0.3, (count, 1))], axis=1)
+    s[0] = [1.2, 0, 0, 0.2]     # touches the max face from outside: lo = n -> dropped
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,count,n", [(1, 500, 1), (1, 2000, 7), (1, 9000, 16), (0, 300, 1), (0, 1500, 5), (1, 0, 3), (1, 4, 32)])
+def test_device_grid_equals_reference_algorithm(ctx, kind, count, n):
+    prims = soup(kind, max(count, 4), 100 + count + n)[:count] if count else np.zeros((0, 9 if kind else 4))
+    bounds = [-1, -1, -1, 1, 1, 1]
+    off_d, ord_d, total = ctx.grid_build(kind, prims, bounds, n)
+    off, order = expected_grid(kind, prims, bounds, n)
+    assert total == len(order)
+    assert np.array_equal(off_d.read(np.uint32), off)
+    assert np.array_equal(ord_d.read(np.uint32, total), order)
+    if total:
+        if kind:
+            nor = np.random.default_rng(5).normal(size=prims.shape)
+            steps = [(0, [0.1, -0.2, 0.3]), (1, [0.5, 0.5, 0.5]), (1, [0.7, 0.8, 0.9]), (2, [0.3, -0.5, 0.1])]   # normalize, scale, translate
+            pb, nb = ctx.grid_gather_triangles(ord_d, total, prims, nor, steps)
+            x = prims.reshape(-1, 3, 3)[order].astype(np.float64)
+            for op, v in steps:
+                v = np.asarray(v, np.float64)
+                x = x - v if op == 0 else x * v if op == 1 else x + v
+            want = np.zeros((total, 3, 4), np.float32)
+            want[:, :, :3] = x.astype(np.float32)
+            assert np.array_equal(pb.read(np.float32).reshape(total, 3, 4).view(np.uint32), want.view(np.uint32))
+            wn = np.zeros((total, 3, 4), np.float32)
+            wn[:, :, :3] = nor.reshape(-1, 3, 3)[order].astype(np.float32)
+            assert np.array_equal(nb.read(np.float32).reshape(total, 3, 4).view(np.uint32), wn.view(np.uint32))
+            pb.release(); nb.release()
+        else:
+            sb = ctx.grid_gather_spheres(ord_d, total, prims)
+            want = np.concatenate([prims[order, :3], (prims[order, 3] * prims[order, 3])[:, None]], axis=1).astype(np.float32)
+            assert np.array_equal(sb.read(np.float32).reshape(total, 4).view(np.uint32), want.view(np.uint32))
+            sb.release()
+        mats = np.arange(len(prims), dtype=np.uint32) * 3 + 1
+        mb = ctx.grid_gather_u32(ord_d, total, mats)
+        assert np.array_equal(mb.read(np.uint32, total), mats[order])
+        mb.release()
+    off_d.release(); ord_d.release()
+
+
+@pytest.mark.gpu
+def test_grid_build_rejects_bad_arguments(ctx, pkg):
+    from raytracing_amd.pyhost import mirt
+    with pytest.raises(mirt.MirtError) as e:
+        ctx.grid_build(1, np.zeros((3, 9)), [0, 0, 0, 1, 1, 1], 0)
+    assert e.value.code == -1
+    off, order, total = ctx.grid_build(1, np.zeros((2, 9)) + 0.5, [0, 0, 0, 1, 1, 1], 2)
+    with pytest.raises(mirt.MirtError) as e:        # order refers to triangles 0 and 1; only one triangle supplied
+        ctx.grid_gather_triangles(order, total, np.zeros((1, 9)))
+    assert e.value.code == -8
+    off.release(); order.release()
