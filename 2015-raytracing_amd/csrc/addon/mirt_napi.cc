@@ -355,6 +355,62 @@ napi_value Zero(napi_env env, napi_callback_info info) {
     if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
     return undef(env);
 }
+// gridBuild(ctx, kind, primsF64Buf, count, nSlabs, boundsFloat64Array(6)) -> {offsets, order, total}
+napi_value GridBuild(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    void *c, *pb = nullptr; uint32_t kind, count, n; void* bd; size_t nb;
+    if (!get_ext(env, argv[0], &c) || !get_u32(env, argv[1], &kind) || !get_u32(env, argv[3], &count) || !get_u32(env, argv[4], &n) ||
+        !get_bytes(env, argv[5], &bd, &nb) || nb < 48)
+        return throw_type(env, "gridBuild(ctx, kind, primsBuf|null, count, nSlabs, Float64Array(6))");
+    get_ext(env, argv[2], &pb);
+    mirt_grid_build_desc d;
+    memset(&d, 0, sizeof d);
+    d.struct_size = sizeof d; d.kind = kind; d.count = count; d.n_slabs = n; d.prims_f64 = (mirt_buf*)pb;
+    memcpy(d.bounds, bd, 48);
+    mirt_buf *off = nullptr, *ord = nullptr; uint32_t total = 0;
+    int rc = mirt_grid_build((mirt_ctx*)c, &d, &off, &ord, &total);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    napi_value o;
+    napi_create_object(env, &o);
+    napi_set_named_property(env, o, "offsets", mk_ext(env, off));
+    napi_set_named_property(env, o, "order", mk_ext(env, ord));
+    napi_set_named_property(env, o, "total", mk_num(env, total));
+    return o;
+}
+// gridGatherTriangles(ctx, order, total, posF64Buf, norF64Buf|null, Int32Array ops, Float64Array vecs, padW) -> {pos, nor}
+napi_value GridGatherTriangles(napi_env env, napi_callback_info info) {
+    ARGS(8);
+    void *c, *ord, *pb, *nb = nullptr; uint32_t total; void *ops, *vecs; size_t nops, nvecs; double pad;
+    if (!get_ext(env, argv[0], &c) || !get_ext(env, argv[1], &ord) || !get_u32(env, argv[2], &total) || !get_ext(env, argv[3], &pb) ||
+        !get_bytes(env, argv[5], &ops, &nops) || !get_bytes(env, argv[6], &vecs, &nvecs) || !get_f64(env, argv[7], &pad))
+        return throw_type(env, "gridGatherTriangles(ctx, order, total, posBuf, norBuf|null, Int32Array, Float64Array, padW)");
+    get_ext(env, argv[4], &nb);
+    const uint32_t nsteps = (uint32_t)(nops / 4);
+    if (nvecs < (size_t)nsteps * 24) return throw_type(env, "gridGatherTriangles: 3 doubles per step");
+    mirt_buf *po = nullptr, *no = nullptr;
+    int rc = mirt_grid_gather_triangles((mirt_ctx*)c, (mirt_buf*)ord, total, (mirt_buf*)pb, (mirt_buf*)nb, nsteps, (const int32_t*)ops, (const double*)vecs,
+                                        (float)pad, &po, nb ? &no : nullptr);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    napi_value o;
+    napi_create_object(env, &o);
+    napi_set_named_property(env, o, "pos", mk_ext(env, po));
+    if (no) napi_set_named_property(env, o, "nor", mk_ext(env, no));
+    return o;
+}
+napi_value GridGather1(napi_env env, napi_callback_info info, bool spheres) {
+    ARGS(4);
+    void *c, *ord, *in; uint32_t total;
+    if (!get_ext(env, argv[0], &c) || !get_ext(env, argv[1], &ord) || !get_u32(env, argv[2], &total) || !get_ext(env, argv[3], &in))
+        return throw_type(env, "gridGather{Spheres,U32}(ctx, order, total, inBuf)");
+    mirt_buf* out = nullptr;
+    int rc = spheres ? mirt_grid_gather_spheres((mirt_ctx*)c, (mirt_buf*)ord, total, (mirt_buf*)in, &out)
+                     : mirt_grid_gather_u32((mirt_ctx*)c, (mirt_buf*)ord, total, (mirt_buf*)in, &out);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    return mk_ext(env, out);
+}
+napi_value GridGatherSpheres(napi_env env, napi_callback_info info) { return GridGather1(env, info, true); }
+napi_value GridGatherU32(napi_env env, napi_callback_info info) { return GridGather1(env, info, false); }
+
 napi_value TimerStart(napi_env env, napi_callback_info info) {
     ARGS(1);
     void* c;
@@ -380,7 +436,8 @@ napi_value Init(napi_env env, napi_value exports) {
         {"bufCreate", BufCreate}, {"bufRelease", BufRelease}, {"bufSize", BufSize}, {"bufWrite", BufWrite}, {"bufRead", BufRead},
         {"programCheck", ProgramCheck}, {"programDialect", ProgramDialect}, {"kernelGet", KernelGet}, {"kernelRelease", KernelRelease}, {"kernelNumArgs", KernelNumArgs},
         {"kernelPreferredMultiple", KernelPreferredMultiple}, {"kernelSetArg", KernelSetArg}, {"enqueue", Enqueue},
-        {"renderPass", RenderPass}, {"seedFill", SeedFill}, {"zero", Zero}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
+        {"renderPass", RenderPass}, {"gridBuild", GridBuild}, {"gridGatherTriangles", GridGatherTriangles},
+        {"gridGatherSpheres", GridGatherSpheres}, {"gridGatherU32", GridGatherU32}, {"seedFill", SeedFill}, {"zero", Zero}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
     };
     for (auto& f : fns) {
         napi_value fn;

@@ -44,6 +44,42 @@ function uploadScene(ctx, q, p) {
   return d;
 }
 
+// The same device-side scene as uploadScene(), but binned ON THE DEVICE from the raw primitives (queue.gridBuild /
+// gridGather*): `sc` is a scene loaded with {deferGrids: true}, `p` its packed header (camera, lights, bounds, materials).
+function buildSceneOnDevice(ctx, q, sc, p) {
+  const d = { bufs: [] };
+  const keep = (b) => { d.bufs.push(b); return b; };
+  const b6 = (b) => [b.min[0], b.min[1], b.min[2], b.max[0], b.max[1], b.max[2]];
+  if (sc.spheres.length) {
+    const f = new Float64Array(sc.spheres.length * 4);
+    sc.spheres.forEach((s, i) => f.set([s.c.x, s.c.y, s.c.z, s.r], 4 * i));
+    const g = q.gridBuild(0, f, b6(sc.sphereBounds), p.n_slabs);
+    d.sph = { prims: keep(q.gridGatherSpheres(g.order, g.total, f)), matid: keep(q.gridGatherU32(g.order, g.total, new Uint32Array(sc.spheres.map((s) => s.matId)))),
+              cellOffsets: keep(g.offsets), bounds: p.sphere_bounds, nSlabs: p.n_slabs };
+    g.order.release();
+  }
+  const tri9 = (T, key) => { const f = new Float64Array(T.length * 9); T.forEach((t, i) => f.set([t[key[0]].x, t[key[0]].y, t[key[0]].z, t[key[1]].x, t[key[1]].y, t[key[1]].z, t[key[2]].x, t[key[2]].y, t[key[2]].z], 9 * i)); return f; };
+  if (sc.triangles.length) {
+    const pos = tri9(sc.triangles, ["p0", "p1", "p2"]), nor = tri9(sc.triangles, ["n0", "n1", "n2"]);
+    const g = q.gridBuild(1, pos, b6(sc.triangleBounds), p.n_slabs);
+    const t = q.gridGatherTriangles(g.order, g.total, pos, nor, [], 0);
+    d.tri = { prims: keep(t.pos), normals: keep(t.nor), matid: keep(q.gridGatherU32(g.order, g.total, new Uint32Array(sc.triangles.map((x) => x.matId)))),
+              cellOffsets: keep(g.offsets), bounds: p.triangle_bounds, nSlabs: p.n_slabs };
+    g.order.release();
+  }
+  d.meshes = sc.meshes.map((m, i) => {
+    const pos = new Float64Array(m.jmesh.positions), nor = new Float64Array(m.jmesh.normals);
+    const g = q.gridBuild(1, pos, b6(m.gridBounds), m.nslabs);      // grid on the untransformed mesh (code.js:106-112)
+    const t = q.gridGatherTriangles(g.order, g.total, pos, nor, m.steps, 0);   // normalize / scale / translate in fp64, then fp32
+    g.order.release();
+    return { prims: keep(t.pos), normals: keep(t.nor), cellOffsets: keep(g.offsets), bounds: p.meshes[i].bounds, nSlabs: m.nslabs, meshMatId: m.matId };
+  });
+  const mat = ctx.createBuffer(webcl.MEM_READ_ONLY, Math.max(p.materials.byteLength, 16));
+  q.enqueueWriteBuffer(mat, false, 0, p.materials.byteLength, p.materials, []);
+  d.material = keep(mat);
+  return d;
+}
+
 class GranularRenderer {
   constructor(packed, opt) {
     opt = opt || {};
@@ -55,6 +91,7 @@ class GranularRenderer {
     this.program.build();
     this.k = {}; this.b = {}; this.gws = {}; this.lws = {};
     this.passes = 1;
+    this.sceneObject = opt.sceneObject || null;
     this._preRender(opt.seeds, opt.seedBase);
   }
   _structSize(name) {  // getStructSize (code.js:1064-1076)
@@ -88,7 +125,7 @@ class GranularRenderer {
     k.initTrace.setArg(5, f32(p.focal_length)); k.initTrace.setArg(6, f32(p.lens_rad)); k.initTrace.setArg(7, u32(p.rays_per_pixel));
     l = this.lws.initTrace = getLocalWS(2, k.initTrace, this.device);
     this.gws.initTrace = [ceilTo(p.width, l[0]), ceilTo(p.height, l[1])];
-    const d = this.dev = uploadScene(ctx, q, p);
+    const d = this.dev = this.sceneObject ? buildSceneOnDevice(ctx, q, this.sceneObject, p) : uploadScene(ctx, q, p);
     if (d.sph) {  // prepareSphereTrace
       k.sphereTrace = prog.createKernel("sphereTrace");
       [u32(n), b.pois, b.rays, d.sph.prims, d.sph.matid, d.sph.cellOffsets, d.sph.bounds, u32(d.sph.nSlabs)].forEach((v, i) => k.sphereTrace.setArg(i, v));
@@ -192,7 +229,7 @@ class FusedRenderer {
     this.npix = this.nrows * p.width;
     this.nrays = this.npix * p.rays_per_pixel;
     const first = this.row0 * p.width * p.rays_per_pixel;
-    this.dev = uploadScene(this.ctx, this.q, p);
+    this.dev = opt.sceneObject ? buildSceneOnDevice(this.ctx, this.q, opt.sceneObject, p) : uploadScene(this.ctx, this.q, p);
     this.seeds = this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 4);
     if (opt.seeds) this.q.enqueueWriteBuffer(this.seeds, false, 0, this.nrays * 4, opt.seeds.subarray(first, first + this.nrays), []);
     else this.q.seedFill(this.seeds, first, this.nrays, opt.seedBase || 0);
@@ -229,7 +266,12 @@ function radianceSums(acu, rpp) {
 
 function renderFile(file, width, height, rpp, passes, opt) {
   opt = opt || {};
-  const packed = scene.packScene(scene.loadSceneFile(file, width, height), width, height, rpp);
+  let packed;
+  if (opt.deviceGrid) {   // host only parses; binning, transforms and fp32 narrowing happen on the device
+    const sc = scene.loadSceneFile(file, width, height, { deferGrids: true });
+    packed = scene.packScene(sc, width, height, rpp, 1, true);
+    opt = Object.assign({}, opt, { sceneObject: sc });
+  } else packed = scene.packScene(scene.loadSceneFile(file, width, height), width, height, rpp);
   const R = opt.granular ? new GranularRenderer(packed, opt) : new FusedRenderer(packed, opt);
   R.q.timerStart();
   for (let i = 0; i < passes; i++) R.executeRender(opt.bounces);

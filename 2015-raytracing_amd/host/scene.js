@@ -304,11 +304,18 @@ function triBox(p, i) {
 
 // Mesh (code.js:94-170): the grid is built on the UNtransformed mesh, then positions and bounds are
 // normalised / scaled / translated in doubles; fp32 narrowing happens at upload.
-function Mesh(jmesh, nslabs, matId) {
+function Mesh(jmesh, nslabs, matId, deferGrid) {
   this.bounds = jmesh.bounds;  // shared object, transformed in place like the reference
   this.ntriangles = jmesh.nTriangles;
   this.nslabs = nslabs;
   this.matId = matId;
+  this.steps = [];             // the fp64 per-axis steps normalize/scale/translate apply, in order (op 0 sub, 1 mul, 2 add)
+  if (deferGrid) {             // device grid build: keep the soup and the UNtransformed bounds the grid is built on
+    this.jmesh = jmesh;
+    this.gridBounds = new Bounds(jmesh.bounds.min, jmesh.bounds.max);
+    this.posData = new Float64Array(0); this.normalData = new Float64Array(0); this.boxSizeData = null;
+    return;
+  }
   const g = buildGrid(jmesh.nTriangles, nslabs, jmesh.bounds, (i) => triBox(jmesh.positions, i));  // splitMeshData (code.js:899-1041)
   const order = g.order, P = jmesh.positions, N = jmesh.normals;
   this.posData = new Float64Array(order.length * 12);
@@ -328,15 +335,17 @@ Mesh.prototype.normalize = function () {
   const b = this.bounds;
   const ctr = [(b.max[0] + b.min[0]) / 2.0, (b.max[1] + b.min[1]) / 2.0, (b.max[2] + b.min[2]) / 2.0];
   const maxdim = 1.0 / Math.max(Math.max(b.max[0] - b.min[0], b.max[1] - b.min[1]), b.max[2] - b.min[2]);
+  this.steps.push({ op: 0, v: ctr }, { op: 1, v: [maxdim, maxdim, maxdim] });
   this._each((v, c) => (v - ctr[c]) * maxdim);
 };
-Mesh.prototype.scale = function (s) { const k = [s.x, s.y, s.z]; this._each((v, c) => v * k[c]); };
-Mesh.prototype.translate = function (t) { const k = [t.x, t.y, t.z]; this._each((v, c) => v + k[c]); };
+Mesh.prototype.scale = function (s) { const k = [s.x, s.y, s.z]; this.steps.push({ op: 1, v: k }); this._each((v, c) => v * k[c]); };
+Mesh.prototype.translate = function (t) { const k = [t.x, t.y, t.z]; this.steps.push({ op: 2, v: k }); this._each((v, c) => v + k[c]); };
 
 // ---------------------------------------------------------------------------------------------
 // loadScene (code.js:723-897).  `readFile(relPath)` resolves mesh files relative to the scene's
 // page directory (the reference fetches "./tri/x.json" relative to index.html).
-function loadScene(xmlText, width, height, readFile) {
+function loadScene(xmlText, width, height, readFile, opt) {
+  const deferGrid = !!(opt && opt.deferGrids);
   const doc = parseXML(xmlText);
   const cam = new Camera();
   const xc = first(doc, "camera");
@@ -381,7 +390,7 @@ function loadScene(xmlText, width, height, readFile) {
   const sceneBounds = new Bounds();
   const meshes = byTag(doc, "mesh").map((e) => {
     const jm = parseMeshJSON(JSON.parse(readFile(xmlStr(e, "file"))));
-    const mesh = new Mesh(jm, xmlNum(e, "nslabs"), lookup[xmlStr(e, "matId")]);
+    const mesh = new Mesh(jm, xmlNum(e, "nslabs"), lookup[xmlStr(e, "matId")], deferGrid);
     if (xmlStr(e, "normalize") == "yes") mesh.normalize();
     mesh.scale(xmlVec3(e, "scale"));
     mesh.translate(xmlVec3(e, "translate"));
@@ -395,13 +404,13 @@ function loadScene(xmlText, width, height, readFile) {
            spheres: spheres, sphereBounds: sphereBounds, triangles: triangles, triangleBounds: triangleBounds, meshes: meshes };
 }
 
-function loadSceneFile(file, width, height) {
+function loadSceneFile(file, width, height, opt) {
   const pageDir = path.dirname(path.dirname(path.resolve(file)));  // scenes/x.xml -> the page directory
   return loadScene(fs.readFileSync(file, "utf8"), width, height, (rel) => {
     let t = fs.readFileSync(path.resolve(pageDir, rel), "utf8");
     if (t.charCodeAt(0) === 0xfeff) t = t.slice(1);
     return t;
-  });
+  }, opt);
 }
 
 // splitMaterialData (code.js:1774-1782)
@@ -413,22 +422,23 @@ function splitMaterialData(scene) {
 
 // Everything the device needs for one scene, as typed arrays -- and, via toJSON(), the same
 // dictionary the test tooling extracts from the reference host (tests compare the two).
-function packScene(scene, width, height, raysPerPixel, nSlabs) {
+function packScene(scene, width, height, raysPerPixel, nSlabs, headerOnly) {
   nSlabs = nSlabs || 1;  // loose spheres / triangles: n_slabs is fixed at 1 in A10 (code.js:399)
   const p = { width: width, height: height, rays_per_pixel: raysPerPixel, n_slabs: nSlabs,
               cam: scene.camera.toFloat32Array(), focal_length: new Float32Array([scene.focal_length])[0],
               lens_rad: new Float32Array([scene.lens_diameter / 2.0])[0], bounds: bounds2AABB(scene.bounds),
               n_spheres: scene.spheres.length, n_triangles: scene.triangles.length };
   if (scene.spheres.length > 0) {
-    const s = splitSphereData(scene, nSlabs);
-    p.spheres = s.spheres; p.s_matid = s.matid; p.s_box = s.offsets; p.sphere_bounds = bounds2AABB(scene.sphereBounds);
+    p.sphere_bounds = bounds2AABB(scene.sphereBounds);
+    if (!headerOnly) { const s = splitSphereData(scene, nSlabs); p.spheres = s.spheres; p.s_matid = s.matid; p.s_box = s.offsets; }
   }
   if (scene.triangles.length > 0) {
-    const t = splitTriangleData(scene, nSlabs);
-    p.t_pos = t.pos; p.t_normal = t.normal; p.t_matid = t.matid; p.t_box = t.offsets; p.triangle_bounds = bounds2AABB(scene.triangleBounds);
+    p.triangle_bounds = bounds2AABB(scene.triangleBounds);
+    if (!headerOnly) { const t = splitTriangleData(scene, nSlabs); p.t_pos = t.pos; p.t_normal = t.normal; p.t_matid = t.matid; p.t_box = t.offsets; }
   }
-  p.meshes = scene.meshes.map((m) => ({ pos: new Float32Array(m.posData), normal: new Float32Array(m.normalData), box: m.boxSizeData,
-                                        matid: m.matId, bounds: bounds2AABB(m.bounds), nslabs: m.nslabs, ntriangles: m.ntriangles }));
+  p.meshes = scene.meshes.map((m) => headerOnly ? { matid: m.matId, bounds: bounds2AABB(m.bounds), nslabs: m.nslabs, ntriangles: m.ntriangles }
+    : ({ pos: new Float32Array(m.posData), normal: new Float32Array(m.normalData), box: m.boxSizeData,
+         matid: m.matId, bounds: bounds2AABB(m.bounds), nslabs: m.nslabs, ntriangles: m.ntriangles }));
   p.lights = scene.lights.map((l) => ({ shadow: l.toShadowInfo(), scene: l.toSceneRenderInfo(), light: l.toLightRenderInfo() }));
   p.materials = splitMaterialData(scene);
   return p;

@@ -83,9 +83,9 @@ class WebCLPlatform {
 }
 
 class WebCLBuffer {
-  constructor(ctx, bytes, flags) {
+  constructor(ctx, bytes, flags, adopt) {
     this.ctx = ctx; this.byteLength = bytes;
-    this.h = wrap(() => native().bufCreate(ctx.h, bytes, flags));
+    this.h = adopt || wrap(() => native().bufCreate(ctx.h, bytes, flags));   // adopt: a buffer the runtime created (grid build)
   }
   release() { if (this.h) { wrap(() => native().bufRelease(this.h)); this.h = null; } }
 }
@@ -161,6 +161,38 @@ class WebCLCommandQueue {
       pixel: desc.pixel ? desc.pixel.h : undefined, radiance: desc.radiance ? desc.radiance.h : undefined,
     });
     wrap(() => native().renderPass(this.ctx.h, d));
+  }
+  // ---- extension: the host's grid builders on the device (mirt_grid_build / mirt_grid_gather_*) ----
+  gridBuild(kind, primsF64, bounds6, nSlabs) {
+    const count = primsF64.length / (kind ? 9 : 4);
+    let pb = null;
+    if (count) { pb = this.ctx.createBuffer(C.MEM_READ_WRITE, primsF64.byteLength); this.enqueueWriteBuffer(pb, false, 0, primsF64.byteLength, primsF64, []); }
+    const r = wrap(() => native().gridBuild(this.ctx.h, kind, pb ? pb.h : null, count, nSlabs, new Float64Array(bounds6)));
+    if (pb) pb.release();
+    return { offsets: new WebCLBuffer(this.ctx, (nSlabs * nSlabs * nSlabs + 1) * 4, 0, r.offsets), order: new WebCLBuffer(this.ctx, Math.max(r.total * 4, 16), 0, r.order), total: r.total };
+  }
+  gridGatherTriangles(order, total, posF64, norF64, steps, padW) {
+    const up = (a) => { const b = this.ctx.createBuffer(C.MEM_READ_WRITE, Math.max(a.byteLength, 16)); if (a.byteLength) this.enqueueWriteBuffer(b, false, 0, a.byteLength, a, []); return b; };
+    const pb = up(posF64), nb = norF64 ? up(norF64) : null;
+    const ops = new Int32Array(steps.map((s) => s.op)), vecs = new Float64Array(steps.length * 3);
+    steps.forEach((s, i) => vecs.set(s.v, 3 * i));
+    const r = wrap(() => native().gridGatherTriangles(this.ctx.h, order.h, total, pb.h, nb ? nb.h : null, ops, vecs, padW || 0));
+    pb.release(); if (nb) nb.release();
+    return { pos: new WebCLBuffer(this.ctx, Math.max(total * 48, 16), 0, r.pos), nor: r.nor ? new WebCLBuffer(this.ctx, Math.max(total * 48, 16), 0, r.nor) : null };
+  }
+  gridGatherSpheres(order, total, sphF64) {
+    const b = this.ctx.createBuffer(C.MEM_READ_WRITE, Math.max(sphF64.byteLength, 16));
+    if (sphF64.byteLength) this.enqueueWriteBuffer(b, false, 0, sphF64.byteLength, sphF64, []);
+    const h = wrap(() => native().gridGatherSpheres(this.ctx.h, order.h, total, b.h));
+    b.release();
+    return new WebCLBuffer(this.ctx, Math.max(total * 16, 16), 0, h);
+  }
+  gridGatherU32(order, total, valuesU32) {
+    const b = this.ctx.createBuffer(C.MEM_READ_WRITE, Math.max(valuesU32.byteLength, 16));
+    if (valuesU32.byteLength) this.enqueueWriteBuffer(b, false, 0, valuesU32.byteLength, valuesU32, []);
+    const h = wrap(() => native().gridGatherU32(this.ctx.h, order.h, total, b.h));
+    b.release();
+    return new WebCLBuffer(this.ctx, Math.max(total * 4, 16), 0, h);
   }
   seedFill(buf, firstRay, count, seedBase) { wrap(() => native().seedFill(this.ctx.h, buf.h, firstRay, count, seedBase || 0)); }
   zero(buf) { wrap(() => native().zero(this.ctx.h, buf.h)); }

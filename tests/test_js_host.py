@@ -109,16 +109,19 @@ def test_webcl_surface_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fused", "granular"])
+@pytest.mark.parametrize("mode", ["fused", "granular", "fused+device-grid", "granular+device-grid"])
 @pytest.mark.parametrize("name", sorted(OWN_SCENES))
 def test_node_render_matches_compiled_reference(tmp_path, name, mode):
-    """scene.xml -> JS host -> N-API addon -> C ABI -> HIP kernels -> frame, against the compiled reference's frame."""
+    """scene.xml -> JS host -> N-API addon -> C ABI -> HIP kernels -> frame, against the compiled reference's frame.
+    `device-grid`: the host only parses; binning, mesh transforms and fp32 narrowing run on the device (mirt_grid_build)."""
     fx, sc = load_fixture(name)
     scene, w, h, rpp = OWN_SCENES[name]
     out = str(tmp_path / "frame.rgba")
     args = [os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", scene), str(w), str(h), str(rpp), "1", out]
-    if mode == "granular":
+    if "granular" in mode:
         args.append("--granular")
+    if "device-grid" in mode:
+        args.append("--device-grid")
     run_node(*args)
     pix = np.fromfile(out, np.uint8).reshape(-1, 4)
     rad = np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)
