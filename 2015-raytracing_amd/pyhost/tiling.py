@@ -27,9 +27,9 @@ def padded_rows(height, world):
 
 def gather_tiles(tile, out=None):
     """all_gather of equally sized 1-D tiles (one per rank) into `out` (world * tile.numel())."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return tile
+    world = dist.get_world_size()
     if out is None:
         out = torch.empty(world * tile.numel(), dtype=tile.dtype, device=tile.device)
     dist.all_gather_into_tensor(out, tile)

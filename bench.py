@@ -87,7 +87,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL path is exercised even with one rank, so `--nproc-per-node 1` rehearses
+    # exactly the code the N-GPU runs execute; a bare `python bench.py` stays free of any process group
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def log(msg):
@@ -118,8 +121,7 @@ def main():
     tile = torch.zeros(max_rows * sc.width * 4, dtype=torch.uint8, device="cuda")
     fr.pixel.release()
     fr.pixel = ctx.wrap(tile.data_ptr(), max_rows * sc.width * 4)
-    frame = torch.empty(world * tile.numel(), dtype=torch.uint8, device="cuda") if world > 1 else None
-    seeds0 = None
+    frame = torch.empty(world * tile.numel(), dtype=torch.uint8, device="cuda") if use_dist else None
 
     def step():
         # a step re-renders the same frame: restore the accumulator and the seeds it started from
@@ -127,12 +129,12 @@ def main():
         ctx.seed_fill(fr.seeds, fr.first_ray, fr.nrays, 0)
         fr.passes = 1
         fr.execute_render(bounces=args.bounces)
-        if world > 1:
+        if use_dist:
             tiling.gather_tiles(tile, frame)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +149,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
 
@@ -184,7 +186,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(packed, log)
     fr.release()
     ctx.destroy()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
