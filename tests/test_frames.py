@@ -119,18 +119,29 @@ def test_node_frame_matches_compiled_reference(tmp_path, name):
     assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), fx["pixel"])
 
 
+def resized(d, w, h):
+    """Same job at another frame size: Camera.set (A07 code.js:55-71) makes width = height * cols/rows; cols, rows ride in .sE/.sF."""
+    d = dict(d, width=w, height=h)
+    cam = list(d["cam"])
+    cam[12] = float(np.float32(cam[13] * (w / h)))
+    cam[14], cam[15] = float(w), float(h)
+    d["cam"] = cam
+    return d
+
+
 @pytest.mark.gpu
-def test_full_size_frames_against_oracle(ctx, pkg):
-    """BASELINE sizes: config 1 is a fixture (512x512); configs 2 and 3 at 1024x1024 / 1920x1080 with our own mesh on the
-    GPU vs the multithreaded CPU oracle (the reference meshes do not travel; same kernels, same sizes)."""
+@pytest.mark.parametrize("name,size", [("frame_a04_parliament_96x64", (1024, 1024)),            # BASELINE config 2: 9144 triangles, brute force
+                                       ("frame_a07_parliament_n16_160x120", (1920, 1080)),       # BASELINE config 3: same mesh, 16^3 grid
+                                       ("frame_a04_own_icosphere_96x64", (1024, 1024)), ("frame_a07_own_octahedra_n3_96x64", (1920, 1080))])
+def test_full_size_frames_against_oracle(ctx, pkg, name, size):
+    """BASELINE configs 2 and 3 at their full sizes, on the reference's house_of_parliament mesh (its packed buffers travel inside
+    the fixture) and on ours: HIP frame == multithreaded CPU oracle, every pixel."""
     from raytracing_amd.pyhost import render
-    for name, (w, h) in (("frame_a04_own_icosphere_96x64", (1024, 1024)), ("frame_a07_own_octahedra_n3_96x64", (1920, 1080))):
-        fx, d = fixture(name)
-        d = dict(d, width=w, height=h)
-        cam = list(d["cam"])
-        cam[12] = float(np.float32(cam[13] * (w / h)))   # Camera.set: width = height * aspect
-        cam[14], cam[15] = float(w), float(h)
-        d["cam"] = cam
-        px, _ = render.render_frame(ctx, render.FramePacked(d))
-        want, _ = F.run_frame("oracle", F.Frame(d))
-        assert np.array_equal(px, want)
+    fx, d = fixture(name)
+    d = resized(d, *size)
+    ctx.timer_start()
+    px, _ = render.render_frame(ctx, render.FramePacked(d))
+    ms = ctx.timer_stop_ms()
+    want, _ = F.run_frame("oracle", F.Frame(d))
+    assert np.array_equal(px, want)
+    print(f"\n{name} at {size[0]}x{size[1]}: {ms:.2f} ms incl. uploads")
