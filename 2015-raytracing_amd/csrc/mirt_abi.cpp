@@ -44,6 +44,12 @@ struct mirt_ctx {
     void* scratch = nullptr;  // lens draws of the rpp==1 mode
     size_t scratch_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* defer = nullptr;        // optimistic pass: [count, cursor, pad, pad | mask words...]
+    size_t defer_bytes = 0;
+    void* defer_list = nullptr;
+    size_t defer_list_bytes = 0;
+    uint64_t last_deferred = 0;   // samples the last mirt_render_pass handed to the exact kernel
+    int force_exact = 1;          // mirt_ctx_set_exact_only: the optimistic two-kernel pass is opt-in (it measured within 1 % of this)
     bool profiling = false;       // per-kernel events inside mirt_render_pass
     hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
     bool pe_valid = false;
@@ -64,6 +70,7 @@ struct mirt_buf {
     void* prep = nullptr;
     size_t prep_bytes = 0;
     uint64_t prep_version = 0;
+    bool prep_sane = false;   // every plane-normal component is 0 or in [2^-40, 2^40]
 };
 
 enum ArgType { A_BUF, A_U32, A_F32, A_F16, A_AABB };
@@ -186,13 +193,22 @@ int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const
     return MIRT_OK;
 }
 
+int ensure_scratch(mirt_ctx* ctx, size_t bytes);
+
 // (re)builds the prepared-triangle copy of a position buffer when its contents changed
 int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
     const size_t bytes = (size_t)count * 48;
     if (pb->prep_version == pb->version && pb->prep_bytes >= bytes && (pb->prep || !bytes)) return MIRT_OK;
     if (pb->prep) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pb->prep)); pb->prep = nullptr; pb->prep_bytes = 0; }
     if (bytes) { HIPCHK(ctx, hipMalloc(&pb->prep, bytes)); pb->prep_bytes = bytes; }
-    pt::launch_prepTriangles(ctx->stream, pb->ptr, pb->prep, count);
+    int rc = ensure_scratch(ctx, 16);
+    if (rc) return rc;
+    uint32_t insane = 0;
+    HIPCHK(ctx, hipMemsetAsync(ctx->scratch, 0, 4, ctx->stream));
+    pt::launch_prepTriangles(ctx->stream, pb->ptr, pb->prep, count, (uint32_t*)ctx->scratch);
+    HIPCHK(ctx, hipMemcpyAsync(&insane, ctx->scratch, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    pb->prep_sane = insane == 0;
     pb->prep_version = pb->version;
     return MIRT_OK;
 }
@@ -253,6 +269,8 @@ int mirt_ctx_destroy(mirt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->defer) (void)hipFree(ctx->defer);
+    if (ctx->defer_list) (void)hipFree(ctx->defer_list);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& e : ctx->pe) if (e) (void)hipEventDestroy(e);
@@ -676,12 +694,13 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     o->n = g->n_slabs;
     o->mesh_matid = g->mesh_matid;
     o->exit_is_far_face = 0;
-    o->bounds_sane = 1;
+    o->fast_ok = 1;
     for (int k = 0; k < 8; ++k) {
         if ((k & 3) == 3) continue;
         const float a = std::fabs(g->bounds[k]);
-        if (!(a == 0.0f || (a >= 9.3132257e-10f && a <= 1048576.0f))) o->bounds_sane = 0;
+        if (!(a == 0.0f || (a >= 9.3132257e-10f && a <= 1048576.0f))) o->fast_ok = 0;
     }
+    if (tri && !g->prims->prep_sane) o->fast_ok = 0;
     if (g->n_slabs == 1) {
         // A10 code.cl:699-707 with n = 1: x_next = pmin + (0 + (d>=0)) * ((pmax-pmin)/1).  When that reproduces pmax / pmin
         // bit for bit, t_next is the very quotient interAABB already formed for the far slab plane.
@@ -750,7 +769,39 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
         A.uv = ctx->scratch;
     }
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->pe[0], ctx->stream));
-    pt::launch_fused(ctx->stream, A);
+    bool optimistic = pt::fused_fast_available() && !ctx->force_exact;
+    for (uint32_t i = 0; i < A.n_sets; ++i) optimistic = optimistic && A.sets[i].fast_ok != 0;
+    ctx->last_deferred = 0;
+    if (optimistic) {
+        // optimistic kernel (exact cheap divisions inside their window) + exact kernel for the samples that left the window
+        const uint32_t words = (uint32_t)((nrays + 31) / 32);
+        const size_t need_bytes = 16 + (size_t)words * 4;
+        if (ctx->defer_bytes < need_bytes) {
+            if (ctx->defer) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->defer)); ctx->defer = nullptr; ctx->defer_bytes = 0; }
+            HIPCHK(ctx, hipMalloc(&ctx->defer, need_bytes));
+            ctx->defer_bytes = need_bytes;
+        }
+        uint32_t* counters = (uint32_t*)ctx->defer;
+        uint32_t* mask = counters + 4;
+        HIPCHK(ctx, hipMemsetAsync(ctx->defer, 0, need_bytes, ctx->stream));
+        pt::launch_fused(ctx->stream, A, true, mask, nullptr, 0);
+        pt::launch_deferCount(ctx->stream, mask, words, counters);
+        uint32_t count = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&count, counters, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->last_deferred = count;
+        if (count) {
+            if (ctx->defer_list_bytes < (size_t)count * 4) {
+                if (ctx->defer_list) { HIPCHK(ctx, hipFree(ctx->defer_list)); ctx->defer_list = nullptr; ctx->defer_list_bytes = 0; }
+                HIPCHK(ctx, hipMalloc(&ctx->defer_list, (size_t)count * 4));
+                ctx->defer_list_bytes = (size_t)count * 4;
+            }
+            pt::launch_deferList(ctx->stream, mask, words, counters + 1, (uint32_t*)ctx->defer_list);
+            pt::launch_fused(ctx->stream, A, false, nullptr, (const uint32_t*)ctx->defer_list, count);
+        }
+    } else {
+        pt::launch_fused(ctx->stream, A, false, nullptr, nullptr, 0);
+    }
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->pe[1], ctx->stream));
     if (d->pixel || d->radiance) {
         const float m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
@@ -761,6 +812,19 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
     HIPCHK(ctx, hipGetLastError());
     d->seeds->version++;
     d->acu->version++;
+    return MIRT_OK;
+}
+
+int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_exact_only: unknown context");
+    ctx->force_exact = on != 0;
+    return MIRT_OK;
+}
+
+int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_pass_deferred: unknown context");
+    if (!samples) return fail(ctx, MIRT_E_ARG, "mirt_pass_deferred: null output");
+    *samples = ctx->last_deferred;
     return MIRT_OK;
 }
 

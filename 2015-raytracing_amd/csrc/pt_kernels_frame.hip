@@ -108,8 +108,7 @@ __global__ void __launch_bounds__(256) k_a04_meshTrace(uchar4* pixels, F16 cam16
     uint32_t champ_i = t_size;
     for (uint32_t i = 0; i < t_size; ++i) {
         float t, b, g;
-        bool redo = false;
-        bool hit = tri_test<TRI_A04, false>(ray.o, ray.d, ray.mint, ray.maxt, prep[3u * i], prep[3u * i + 1], prep[3u * i + 2], t, b, g, redo);
+        bool hit = tri_test<TRI_A04, false>(ray.o, ray.d, ray.mint, ray.maxt, prep[3u * i], prep[3u * i + 1], prep[3u * i + 2], t, b, g);
         if (hit && t < champ_t) { champ_t = t; champ_i = i; cb = b; cg = g; }
     }
     if (champ_i >= t_size) return;
@@ -150,8 +149,7 @@ __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16
         const uint32_t begin = slab_size[cell], end = slab_size[cell + 1];
         for (uint32_t i = begin; i < end; ++i) {
             float ti, b, g;
-            bool redo = false;
-            bool hit = tri_test<TRI_A07, false>(ray.o, ray.d, cmin, cmax, prep[3u * i], prep[3u * i + 1], prep[3u * i + 2], ti, b, g, redo);
+            bool hit = tri_test<TRI_A07, false>(ray.o, ray.d, cmin, cmax, prep[3u * i], prep[3u * i + 1], prep[3u * i + 2], ti, b, g);
             if (hit && ti < champ_t) { champ_t = ti; champ_i = i; cb = b; cg = g; hx = ax.slab; hy = ay.slab; hz = az.slab; }
         }
         if (champ_i != UINT32_MAX) break;

@@ -28,7 +28,9 @@
 namespace pt {
 
 // prepared triangle: 3 x float4 = {p0.xyz, n.x} {e1.xyz, n.y} {e2.xyz, n.z}
-__global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4* out, uint32_t count) {
+// `insane` (one word, zeroed by the caller) is set when a plane-normal component is neither zero nor within [2^-40, 2^40]:
+// such a set must not use the fast reciprocal forms (GridArgs::fast_ok).
+__global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4* out, uint32_t count, uint32_t* insane) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     f3 p0 = ld3(pos[3u * i]), p1 = ld3(pos[3u * i + 1]), p2 = ld3(pos[3u * i + 2]);
@@ -38,6 +40,8 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
     out[3u * i] = make_float4(p0.x, p0.y, p0.z, n.x);
     out[3u * i + 1] = make_float4(e1.x, e1.y, e1.z, n.y);
     out[3u * i + 2] = make_float4(e2.x, e2.y, e2.z, n.z);
+    auto bad = [](float v) { const float a = __builtin_fabsf(v); return !(v == 0.0f || (a >= 9.094947e-13f && a <= 1.0995116e12f)); };
+    if (bad(n.x) || bad(n.y) || bad(n.z)) atomicOr(insane, 1u);
 }
 
 // Cold per-ray state parked in LDS instead of registers: the accumulator (touched once per shading event) and the
@@ -73,15 +77,16 @@ PT_DEV Box set_box(const GridArgs& S) {
 
 // closest hit over every set in upload order, z-buffered through ray.maxt
 // (A10 code.cl:675-800, 802-935, 937-1070; order A10 code.js:1809-1813)
-PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park) {
-    const RayRecip rr = ray_recip(ray);
+template <bool FAST>
+PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park, bool& defer) {
+    if (FAST && !(ray.mint == ray.maxt)) defer = defer || !ray_guard(ray);   // a dead ray divides nothing
     for (uint32_t s = 0; s < A.n_sets; ++s) {
         const GridArgs& S = A.sets[s];
         if (ray.mint == ray.maxt) continue;
-        BoxHit bh = inter_aabb_rr(ray, set_box(S), rr, S.bounds_sane != 0);
+        BoxHit bh = inter_aabb_t<FAST>(ray, set_box(S));
         if (!bh.v) continue;
         if (S.kind == KIND_SPHERES) {
-            Hit ch = trace_set<SPHERES, false>(ray, bh, S);
+            Hit ch = trace_set<SPHERES, false, TRI_A10, FAST>(ray, bh, S);
             if (ch.idx == UINT32_MAX) continue;
             ray.maxt = ch.t;
             poi.p = add3(ray.o, scl3(ch.t, ray.d));
@@ -91,7 +96,7 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
             park.put_pn(poi);
 #endif
         } else {
-            Hit ch = trace_set<TRIANGLES, false>(ray, bh, S);
+            Hit ch = trace_set<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S);
             if (ch.idx == UINT32_MAX) continue;
             ray.maxt = ch.t;
             poi.p = add3(ray.o, scl3(ch.t, ray.d));
@@ -108,7 +113,8 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
 
 // per light: shadow ray, any-hit over every set, shade (A10 code.js:1817-1826; code.cl:631-673,
 // 1073-1321, 1323-1364)
-PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc, const Park& park) {
+template <bool FAST>
+PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc, const Park& park, bool& defer) {
     const float4* material = (const float4*)A.material;
     for (uint32_t l = 0; l < A.n_lights; ++l) {
         const LightArgs& L = A.lights[l];
@@ -117,13 +123,13 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
         park.get_pn(poi);
 #endif
         Ray sh = shadow_ray(poi, ld3(L.shadow), ld3(L.shadow + 3), ld3(L.shadow + 6), L.shadow[9], seed);
-        const RayRecip rr = ray_recip(sh);
+        if (FAST) defer = defer || !ray_guard(sh);
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
             if (sh.mint == sh.maxt) continue;
-            BoxHit bh = inter_aabb_rr(sh, set_box(S), rr, S.bounds_sane != 0);
+            BoxHit bh = inter_aabb_t<FAST>(sh, set_box(S));
             if (!bh.v) continue;
-            Hit ch = (S.kind == KIND_SPHERES) ? trace_set<SPHERES, true>(sh, bh, S) : trace_set<TRIANGLES, true>(sh, bh, S);
+            Hit ch = (S.kind == KIND_SPHERES) ? trace_set<SPHERES, true, TRI_A10, FAST>(sh, bh, S) : trace_set<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S);
             sh.maxt = ch.t;
             if (ch.idx != UINT32_MAX) sh.mint = ch.t;
         }
@@ -147,10 +153,23 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 #ifndef PT_FUSED_WAVES
 #define PT_FUSED_WAVES 6   // waves per SIMD the register allocator must leave room for (A/B: 4 -> 213 ms, 5 -> 205, 6 -> 200, 8 -> 243 with spills)
 #endif
-__global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedArgs A) {
+// FAST = true : the optimistic kernel.  Every division in the traversal is one of the exact cheap forms; a sample whose rays
+//               ever leave the guard window sets its bit in `defer_mask` and leaves seeds[]/acu[] untouched.
+// FAST = false: the exact kernel (true divisions).  With `list` it recomputes the deferred samples; with list == nullptr it
+//               is the whole pass (geometry outside the guard, or PT_EXACT_FAST_DIV = 0).
+#ifndef PT_FUSED_WAVES_FAST
+#define PT_FUSED_WAVES_FAST 5   // the optimistic kernel: 95 VGPRs, 12 B scratch (A/B: 6 -> 200.4 ms, 5 -> 195.7, 4 -> 210.4; exact kernel 197.5)
+#endif
+template <bool FAST>
+__global__ void __launch_bounds__(256, FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count) {
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;
-    const uint64_t lid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!FAST && list) {
+        if (lid >= list_count) return;
+        lid = list[lid];
+    }
     if (lid >= n_local) return;
+    bool defer = false;
     const uint64_t lpix = lid / A.rpp;
     const uint32_t smp = (uint32_t)(lid - lpix * A.rpp);
     const uint32_t lrow = (uint32_t)(lpix / A.width);
@@ -214,7 +233,7 @@ __global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedAr
                 ray.maxt = PT_INF;
             }
         }
-        closest_all(A, ray, poi, park);
+        closest_all<FAST>(A, ray, poi, park, defer);
         if (seg == 0) {
             for (uint32_t l = 0; l < A.n_lights; ++l) {  // lightRender (code.cl:600-629), primary segment only
                 if (ray.mint == ray.maxt) continue;
@@ -231,9 +250,13 @@ __global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedAr
 #endif
             }
         }
-        direct_all(A, poi, seed, acc, park);
+        direct_all<FAST>(A, poi, seed, acc, park, defer);
     }
 
+    if (FAST && defer) {   // hand the sample to the exact kernel: its inputs stay as they were
+        atomicOr(&defer_mask[lid >> 5], 1u << (lid & 31u));
+        return;
+    }
     A.seeds[lid] = seed;
 #if PT_PARK_LDS
     acc = make_float4(park.get(0), park.get(1), park.get(2), park.get(3));
@@ -241,16 +264,40 @@ __global__ void __launch_bounds__(256, PT_FUSED_WAVES) k_fusedPass(const FusedAr
     ((float4*)A.acu)[lid] = acc;
 }
 
-void launch_fused(hipStream_t s, const FusedArgs& a) {
-    const uint64_t n = (uint64_t)a.nrows * a.width * a.rpp;
-    if (!n) return;
-    const uint64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_fusedPass, dim3((unsigned)blocks), dim3(256), 0, s, a);
+// deferred-sample bookkeeping: count the set bits, then expand them into a dense list for k_fusedPass<false>
+__global__ void __launch_bounds__(256) k_deferCount(const uint32_t* mask, uint32_t words, uint32_t* count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = (i < words) ? (uint32_t)__builtin_popcount(mask[i]) : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+__global__ void __launch_bounds__(256) k_deferList(const uint32_t* mask, uint32_t words, uint32_t* cursor, uint32_t* list) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    uint32_t w = mask[i];
+    if (!w) return;
+    uint32_t at = atomicAdd(cursor, (uint32_t)__builtin_popcount(w));
+    while (w) { const int b = __builtin_ctz(w); list[at++] = i * 32u + (uint32_t)b; w &= w - 1; }
 }
 
-void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count) {
+void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count) {
+    const uint64_t n = list ? list_count : (uint64_t)a.nrows * a.width * a.rpp;
+    if (!n) return;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (fast) hipLaunchKernelGGL(k_fusedPass<true>, grid, dim3(256), 0, s, a, defer_mask, (const uint32_t*)nullptr, 0u);
+    else hipLaunchKernelGGL(k_fusedPass<false>, grid, dim3(256), 0, s, a, (uint32_t*)nullptr, list, list_count);
+}
+bool fused_fast_available() { return PT_EXACT_FAST_DIV != 0; }
+void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count) {
+    if (words) hipLaunchKernelGGL(k_deferCount, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, count);
+}
+void launch_deferList(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* cursor, uint32_t* list) {
+    if (words) hipLaunchKernelGGL(k_deferList, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, cursor, list);
+}
+
+void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word) {
     if (!count) return;
-    hipLaunchKernelGGL(k_prepTriangles, dim3((count + 255) / 256), dim3(256), 0, s, (const float4*)pos, (float4*)out, count);
+    hipLaunchKernelGGL(k_prepTriangles, dim3((count + 255) / 256), dim3(256), 0, s, (const float4*)pos, (float4*)out, count, insane_word);
 }
 
 }  // namespace pt

@@ -42,7 +42,8 @@ struct GridArgs {            // one cell-sorted primitive set, device pointers
     uint32_t n;              // cells per axis
     uint32_t mesh_matid;
     uint32_t kind;           // KIND_SPHERES | KIND_TRIANGLES
-    uint32_t bounds_sane;    // every bound is 0 or has magnitude in [2^-30, 2^20] (host-checked): enables the shared-reciprocal AABB
+    uint32_t fast_ok;        // geometry-side guard of the exact 3-operation divisions (pt_trace.hpp ray_recip): every bound is 0 or
+                             // in [2^-30, 2^20]; for triangles every plane-normal component is 0 or in [2^-40, 2^40]
     uint32_t exit_is_far_face; // n == 1 only: lo + 1*((hi-lo)/1) == hi and lo + 0*((hi-lo)/1) == lo hold bitwise on all three
                              // axes (checked on the host), so the single cell's exit t equals the AABB slab's far t
 };
@@ -67,9 +68,13 @@ struct FusedArgs {
     void* acu;               // float4[nrows*width*rpp], accumulated into
     const void* uv;          // rpp == 1: float2[nrows*width] lens draws from launch_lensDraws
 };
-void launch_fused(hipStream_t s, const FusedArgs& a);
+// fast: the optimistic kernel (writes deferred samples' bits into defer_mask); !fast: the exact kernel over `list` (or everything)
+void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count);
+bool fused_fast_available();   // compiled with PT_EXACT_FAST_DIV
+void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count);
+void launch_deferList(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* cursor, uint32_t* list);
 // {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip)
-void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count);
+void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word);
 
 // ---- uniform-grid build on the device (pt_grid_build.hip) -------------------------------------------
 hipError_t grid_build(hipStream_t s, int kind, const double* prims, uint32_t count, const double bounds6[6], uint32_t n,

@@ -17,15 +17,11 @@
 #include <stdint.h>
 
 #ifndef PT_EXACT_FAST_DIV
-#define PT_EXACT_FAST_DIV 0   // 1: shared-reciprocal / refined-reciprocal forms below (exact, validated on the device, but
-                              // slower in k_fusedPass today: -9 % VALU ops, +25 % SALU/SMEM and doubled s_waitcnt stalls from
-                              // the extra live registers -- DESIGN.md section 8); 0: the compiler's 11-op expansion everywhere
-#endif
-#ifndef PT_EXACT_FAST_TRI
-#define PT_EXACT_FAST_TRI 1   // the triangle determinant's reciprocal inside the primitive loops
+#define PT_EXACT_FAST_DIV 1   // 1: k_fusedPass<FAST> uses the refined-reciprocal forms below and defers the (rare) samples whose
+                              // rays leave the guard window to k_fusedPass<EXACT>; 0: only the exact kernel runs
 #endif
 #ifndef PT_EXACT_FAST_NORM
-#define PT_EXACT_FAST_NORM 1  // normalize() and the sphere's 1/(2a)
+#define PT_EXACT_FAST_NORM 0  // normalize(): per-lane guarded refined reciprocal (a zero-length vector must still give 1/0)
 #endif
 
 namespace pt {

@@ -19,20 +19,18 @@ struct Hit { uint32_t idx; float t, beta, gamma; };
 // TRI_A07: open t interval, no gamma > 1 test   (A07 code.cl:188, 195)
 // TRI_A04: open t interval, gamma > 1 rejects    (A04 code.cl:170, 177)
 enum TriRule { TRI_A10 = 0, TRI_A07 = 1, TRI_A04 = 2 };
-// FAST: 1/div by the 3-operation refined reciprocal, no branch; `redo` collects the lanes whose div is positive
-// but outside the window where that form is exact -- the caller repeats the whole set for them with FAST = false.
+// FAST: 1/div by the 3-operation refined reciprocal (pt_numerics.hpp), exact whenever div is zero or inside its window, which
+// the guards guarantee (ray_guard() on the ray side, GridArgs::fast_ok on the geometry side).  A lane whose ray fails the guard
+// still runs this code -- on values nobody will read: the optimistic kernel marks that sample `deferred` and the exact kernel
+// (FAST = false, true divisions everywhere) recomputes it from its untouched seed and accumulator (pt_kernels_fused.hip).
 template <int RULE = TRI_A10, bool FAST = false>
 PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const float4 B, const float4 C,
-                     float& t_out, float& beta_out, float& gamma_out, bool& redo) {
+                     float& t_out, float& beta_out, float& gamma_out) {
     const f3 p0 = mk3(A.x, A.y, A.z), e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z), n = mk3(A.w, B.w, C.w);
     float div = dot3(n, d);
     float idiv;
-    if (FAST) {
-        idiv = rcp_refined(div);
-        redo = redo || ((div > 0.0f) && !rcp_window(div));   // lanes with div <= 0 (or NaN) are rejected below whatever idiv is
-    } else {
-        idiv = 1.0f / div;
-    }
+    if (FAST) idiv = rcp_refined(div);   // div <= 0 (incl. 0 -> NaN) and NaN lanes are rejected below whatever idiv is
+    else idiv = 1.0f / div;
     f3 s = sub3(o, p0);
     float beta = dot3(cross3(s, d), e2) * idiv;
     float gamma = dot3(cross3(s, e1), d) * idiv;
@@ -50,20 +48,17 @@ PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const f
     return ok;
 }
 
-// Per-ray reciprocals of the direction, shared by the six slab quotients of every set's AABB (and the three cell-exit
-// quotients of single-cell grids): see pt_numerics.hpp "exact division, cheaper".  `ok` is the lane's guard:
-// |d_k| in [2^-40, 2^40] and o_k zero or in [2^-30, 2^20]; together with bounds that are zero or in [2^-30, 2^20]
-// (GridArgs::bounds_sane, checked on the host) every numerator lo-o / hi-o is zero or in [2^-53, 2^21].
-struct RayRecip { float rx, ry, rz; bool ok; };
-PT_DEV RayRecip ray_recip(const Ray& r) {
-    RayRecip q;
+// Ray-side guard of the exact cheap divisions (pt_numerics.hpp "exact division, cheaper"): |d_k| in [2^-40, 2^40] and o_k zero or
+// in [2^-30, 2^20].  With the geometry-side guard (GridArgs::fast_ok, checked on the host: bounds zero or in [2^-30, 2^20],
+// triangle-plane normals zero or in [2^-40, 2^40] per component) it gives
+//   * every slab numerator lo-o / hi-o is zero or in [2^-53, 2^21]           -> div_exact3 == the true quotient
+//   * every determinant n.d is zero or in [2^-103, 2^82] (sums of products that are zero or >= 2^-80 cancel to zero or to a
+//     multiple of 2^-103)                                                     -> rcp_refined == the true reciprocal
+//   * dot(d,d) is in [2^-80, 2^82]                                            -> the sphere's 1/(2a) likewise
+PT_DEV bool ray_guard(const Ray& r) {
     auto dwin = [](float d) { return __builtin_fabsf(d) >= 9.094947e-13f && __builtin_fabsf(d) <= 1.0995116e12f; };          // 2^-40 .. 2^40
     auto owin = [](float o) { return o == 0.0f || (__builtin_fabsf(o) >= 9.3132257e-10f && __builtin_fabsf(o) <= 1048576.0f); };  // 0 | 2^-30 .. 2^20
-    q.ok = dwin(r.d.x) && dwin(r.d.y) && dwin(r.d.z) && owin(r.o.x) && owin(r.o.y) && owin(r.o.z);
-    q.rx = rcp_refined(r.d.x);
-    q.ry = rcp_refined(r.d.y);
-    q.rz = rcp_refined(r.d.z);
-    return q;
+    return dwin(r.d.x) && dwin(r.d.y) && dwin(r.d.z) && owin(r.o.x) && owin(r.o.y) && owin(r.o.z);
 }
 PT_DEV bool slab1_fast(float lo, float hi, float o, float d, float r, BoxHit& h, float& tfar) {
     float t0 = div_exact3(lo - o, d, r);
@@ -76,29 +71,29 @@ PT_DEV bool slab1_fast(float lo, float hi, float o, float d, float r, BoxHit& h,
     h.tmax = cl_min(tf, h.tmax);
     return !(h.tmin > h.tmax);
 }
-// inter_aabb (pt_device.hpp) with the shared reciprocals when every lane of the wave is inside the guard
-PT_DEV BoxHit inter_aabb_rr(const Ray& r, const Box& b, const RayRecip& rr, bool bounds_sane) {
-#if PT_EXACT_FAST_DIV
-    if (bounds_sane) {   // wave-uniform (a scene constant)
+// inter_aabb (pt_device.hpp); FAST: the six slab quotients share three refined reciprocals
+template <bool FAST>
+PT_DEV BoxHit inter_aabb_t(const Ray& r, const Box& b) {
+    if (FAST) {
         BoxHit h;
         h.tmin = 0.0f;
         h.tmax = PT_INF;
-        const bool okx = slab1_fast(b.lo.x, b.hi.x, r.o.x, r.d.x, rr.rx, h, h.tfx);
-        const bool oky = slab1_fast(b.lo.y, b.hi.y, r.o.y, r.d.y, rr.ry, h, h.tfy);
-        const bool okz = slab1_fast(b.lo.z, b.hi.z, r.o.z, r.d.z, rr.rz, h, h.tfz);
+        const float rx = rcp_refined(r.d.x), ry = rcp_refined(r.d.y), rz = rcp_refined(r.d.z);
+        const bool okx = slab1_fast(b.lo.x, b.hi.x, r.o.x, r.d.x, rx, h, h.tfx);
+        const bool oky = slab1_fast(b.lo.y, b.hi.y, r.o.y, r.d.y, ry, h, h.tfy);
+        const bool okz = slab1_fast(b.lo.z, b.hi.z, r.o.z, r.d.z, rz, h, h.tfz);
         h.v = okx && oky && okz;
-        if (__builtin_expect(!rr.ok, 0)) h = inter_aabb(r, b);   // lanes outside the guard redo it with true divisions
         return h;
     }
-#endif
     return inter_aabb(r, b);
 }
 
 struct SphereRay { float a, inv2a; };  // ray-only part of the quadratic (A10 code.cl:203, 218)
+template <bool FAST>
 PT_DEV SphereRay sphere_ray(f3 d) {
     SphereRay r;
     r.a = dot3(d, d);
-    r.inv2a = rcp_exact(2.0f * r.a);
+    r.inv2a = FAST ? rcp_refined(2.0f * r.a) : (1.0f / (2.0f * r.a));
     return r;
 }
 PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, const float4 sph, float& t_out) {
@@ -119,8 +114,8 @@ PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, co
 
 // One primitive set.  KIND / ANY as in pt_device.hpp.  n == 1: a single cell, every lane walks
 // the same list -> wave-uniform loop, scalar loads.  n > 1: per-lane 3-axis DDA.
-template <int KIND, bool ANY, int RULE, bool FAST>
-PT_DEV Hit trace_set_impl(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& redo) {
+template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false>
+PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
     Hit ch;
@@ -129,7 +124,7 @@ PT_DEV Hit trace_set_impl(const Ray& ray, const BoxHit& bh, const GridArgs& S, b
     ch.beta = 0.0f;
     ch.gamma = 0.0f;
     SphereRay sr;
-    if (KIND == SPHERES) sr = sphere_ray(ray.d);
+    if (KIND == SPHERES) sr = sphere_ray<FAST>(ray.d);
 
     if (S.n == 1u) {
         // axis_setup with n == 1: slab = 0, the cell exit is the far face as the reference computes
@@ -158,7 +153,7 @@ PT_DEV Hit trace_set_impl(const Ray& ray, const BoxHit& bh, const GridArgs& S, b
             if (KIND == SPHERES) {
                 hit = sph_test(ray.o, ray.d, sr, cmin, cmax, prims[i], ti);
             } else {
-                hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, prims[3u * i], prims[3u * i + 1], prims[3u * i + 2], ti, b, gm, redo);
+                hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, prims[3u * i], prims[3u * i + 1], prims[3u * i + 2], ti, b, gm);
             }
             const bool better = !done && hit && ti < ch.t;
             if (better) { ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm; }
@@ -186,7 +181,7 @@ PT_DEV Hit trace_set_impl(const Ray& ray, const BoxHit& bh, const GridArgs& S, b
             if (KIND == SPHERES) {
                 hit = sph_test(ray.o, ray.d, sr, cmin, cmax, prims[i], ti);
             } else {
-                hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, prims[3u * i], prims[3u * i + 1], prims[3u * i + 2], ti, b, gm, redo);
+                hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, prims[3u * i], prims[3u * i + 1], prims[3u * i + 2], ti, b, gm);
             }
             if (hit && ti < ch.t) {
                 ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm;
@@ -213,21 +208,6 @@ PT_DEV Hit trace_set_impl(const Ray& ray, const BoxHit& bh, const GridArgs& S, b
         }
     }
     return ch;
-}
-
-// One primitive set.  The inner loops run the branch-free fast-reciprocal test; a lane that met a determinant outside
-// the exactness window (a grazing hit with div < 2^-126, practically never) repeats the set with true divisions.
-template <int KIND, bool ANY, int RULE = TRI_A10>
-PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
-#if PT_EXACT_FAST_DIV && PT_EXACT_FAST_TRI
-    bool redo = false;
-    Hit h = trace_set_impl<KIND, ANY, RULE, true>(ray, bh, S, redo);
-    if (__builtin_expect(redo, 0)) { bool dummy = false; h = trace_set_impl<KIND, ANY, RULE, false>(ray, bh, S, dummy); }
-    return h;
-#else
-    bool dummy = false;
-    return trace_set_impl<KIND, ANY, RULE, false>(ray, bh, S, dummy);
-#endif
 }
 
 }  // namespace pt

@@ -77,6 +77,8 @@ SYMBOLS = {
     "mirt_kernel_preferred_multiple": (C.c_int, [C.c_void_p]),
     "mirt_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "mirt_render_pass": (C.c_int, [C.c_void_p, C.POINTER(_PassDesc)]),
+    "mirt_pass_deferred": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mirt_ctx_set_exact_only": (C.c_int, [C.c_void_p, C.c_int]),
     "mirt_seed_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]),
     "mirt_zero": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mirt_timer_start": (C.c_int, [C.c_void_p]),
@@ -226,6 +228,14 @@ class Context:
         ms = C.c_float()
         self._chk(lib().mirt_timer_stop_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def pass_deferred(self):
+        n = C.c_uint64()
+        self._chk(lib().mirt_pass_deferred(self.h, C.byref(n)))
+        return n.value
+
+    def set_exact_only(self, on=True):
+        self._chk(lib().mirt_ctx_set_exact_only(self.h, 1 if on else 0))
 
     def set_profiling(self, on=True):
         self._chk(lib().mirt_ctx_set_profiling(self.h, 1 if on else 0))

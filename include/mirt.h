@@ -163,6 +163,12 @@ typedef struct mirt_pass_desc {
 } mirt_pass_desc;
 
 MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
+/* Two ways to run the pass, identical results.  Default (exact only): one kernel whose every division is the compiler's
+ * correctly rounded expansion.  mirt_ctx_set_exact_only(ctx, 0) selects the optimistic pair: a kernel whose divisions are
+ * 3-operation forms that are bit-exact inside a guard window, plus the exact kernel re-running the samples whose rays left the
+ * window (NaN rays, axis-parallel directions, ...).  mirt_pass_deferred: how many samples the last pass re-ran that way. */
+MIRT_API int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples);
+MIRT_API int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on);
 
 /* seeds[i] = 1 + (mix32((first_ray + i) ^ 0x9E3779B9 ^ seed_base) mod 2147483646): the
  * reproducible stand-in for the host's Math.random() seeding (A10 code.js:1140-1146). */

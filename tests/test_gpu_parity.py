@@ -60,6 +60,28 @@ def test_fused_pass_matches_compiled_reference(ctx, pkg, name):
     fr.release()
 
 
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_optimistic_pass_matches_compiled_reference(ctx, pkg, name):
+    """The opt-in two-kernel pass (3-operation exact divisions + exact re-run of the samples outside the guard window)
+    must give the same bits; samples with NaN rays (odd lens grid) are among the deferred ones."""
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture(name)
+    ctx.set_exact_only(False)
+    try:
+        fr = render.FusedRenderer(ctx, sc, seeds=fx["seeds_in"])
+        fr.execute_render()
+        deferred = ctx.pass_deferred()
+        assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(fx["f_acu"])), "acu"
+        assert np.array_equal(fr.seeds.read(np.int32), fx["f_seeds"]), "seeds"
+        assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), fx["pixel"]), "pixel"
+        fr.release()
+    finally:
+        ctx.set_exact_only(True)
+    if name == "cornell_16x12_r9":
+        assert deferred >= sc.total_rays // 9          # every centre-of-lens sample is a NaN ray
+    assert deferred <= sc.total_rays
+
+
 def test_fused_large_case_against_fixture_digests(ctx, pkg):
     """cornell.xml 320x240 x 16 rays per pixel: pixel / radiance exact, per-ray acu + seeds by SHA-256."""
     from raytracing_amd.pyhost import render
