@@ -8,6 +8,10 @@
 #include "pt_device.hpp"
 #include "pt_launch.hpp"
 
+#ifndef PT_UNROLL_UNIFORM
+#define PT_UNROLL_UNIFORM 1   // primitives per trip of the wave-uniform loops
+#endif
+
 namespace pt {
 
 struct Hit { uint32_t idx; float t, beta, gamma; };
@@ -147,6 +151,9 @@ PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
         const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
         bool done = false;
+#if PT_UNROLL_UNIFORM > 1
+#pragma unroll PT_UNROLL_UNIFORM
+#endif
         for (uint32_t i = begin; i < end; ++i) {
             float ti, b = 0.0f, gm = 0.0f;
             bool hit;

@@ -76,6 +76,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON: native libraries that print banners to fd 1 (RCCL does at init) go to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -188,6 +193,9 @@ def main():
     ctx.destroy()
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
 
