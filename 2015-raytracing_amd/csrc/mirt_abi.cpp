@@ -195,6 +195,20 @@ int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const
 
 int ensure_scratch(mirt_ctx* ctx, size_t bytes);
 
+// n == 1 only.  A10 code.cl:699-707: x_next = pmin + (0 + (d>=0)) * ((pmax-pmin)/1).  When that reproduces pmax / pmin bit for
+// bit on all three axes, the single cell's exit t is the very quotient interAABB already formed for the far slab plane.
+uint32_t exit_is_far_face(const float* b8, uint32_t n) {
+    if (n != 1) return 0;
+    bool exact = true;
+    for (int k = 0; k < 3; ++k) {
+        volatile float lo = b8[k], hi = b8[4 + k];
+        volatile float delta = (hi - lo) / 1.0f;
+        volatile float up = lo + 1.0f * delta, dn = lo + 0.0f * delta;
+        exact = exact && (up == hi) && (dn == lo) && (up == up);
+    }
+    return exact ? 1u : 0u;
+}
+
 // (re)builds the prepared-triangle copy of a position buffer when its contents changed
 int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
     const size_t bytes = (size_t)count * 48;
@@ -544,7 +558,7 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
             if ((rc = need(ctx, "sphereTrace pois", BUF(1), (uint64_t)cnt * kPoiBytes))) return rc;
             if ((rc = need(ctx, "sphereTrace rays", BUF(2), (uint64_t)cnt * kRayBytes))) return rc;
             if ((rc = check_grid(ctx, "sphereTrace grid", BUF(5), U(7), BUF(3), 16, nullptr, BUF(4)))) return rc;
-            pt::launch_closest(st, pt::KIND_SPHERES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, nullptr, BUF(4)->ptr, 0, BUF(5)->ptr, V(6), U(7), g0);
+            pt::launch_closest(st, pt::KIND_SPHERES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, nullptr, BUF(4)->ptr, 0, BUF(5)->ptr, V(6), U(7), exit_is_far_face(V(6), U(7)), g0);
             break;
         }
         case K_triangleTrace: {
@@ -552,7 +566,8 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
             if ((rc = need(ctx, "triangleTrace pois", BUF(1), (uint64_t)cnt * kPoiBytes))) return rc;
             if ((rc = need(ctx, "triangleTrace rays", BUF(2), (uint64_t)cnt * kRayBytes))) return rc;
             if ((rc = check_grid(ctx, "triangleTrace grid", BUF(6), U(8), BUF(3), 48, BUF(4), BUF(5)))) return rc;
-            pt::launch_closest(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, BUF(4)->ptr, BUF(5)->ptr, 0, BUF(6)->ptr, V(7), U(8), g0);
+            if ((rc = ensure_prepared(ctx, BUF(3), BUF(6)->off_last))) return rc;
+            pt::launch_closest(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->prep, BUF(4)->ptr, BUF(5)->ptr, 0, BUF(6)->ptr, V(7), U(8), exit_is_far_face(V(7), U(8)), g0);
             break;
         }
         case K_meshTrace: {
@@ -560,7 +575,8 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
             if ((rc = need(ctx, "meshTrace pois", BUF(1), (uint64_t)cnt * kPoiBytes))) return rc;
             if ((rc = need(ctx, "meshTrace rays", BUF(2), (uint64_t)cnt * kRayBytes))) return rc;
             if ((rc = check_grid(ctx, "meshTrace grid", BUF(5), U(8), BUF(3), 48, BUF(4), nullptr))) return rc;
-            pt::launch_closest(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, BUF(4)->ptr, nullptr, U(6), BUF(5)->ptr, V(7), U(8), g0);
+            if ((rc = ensure_prepared(ctx, BUF(3), BUF(5)->off_last))) return rc;
+            pt::launch_closest(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->prep, BUF(4)->ptr, nullptr, U(6), BUF(5)->ptr, V(7), U(8), exit_is_far_face(V(7), U(8)), g0);
             break;
         }
         case K_lightRender: {
@@ -583,14 +599,15 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
             uint32_t cnt = std::min(g0, U(0));
             if ((rc = need(ctx, "sphereShadowTrace shadow", BUF(1), (uint64_t)cnt * kRayBytes))) return rc;
             if ((rc = check_grid(ctx, "sphereShadowTrace grid", BUF(3), U(5), BUF(2), 16, nullptr, nullptr))) return rc;
-            pt::launch_anyhit(st, pt::KIND_SPHERES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, V(4), U(5), g0);
+            pt::launch_anyhit(st, pt::KIND_SPHERES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, V(4), U(5), exit_is_far_face(V(4), U(5)), g0);
             break;
         }
         case K_triangleShadowTrace: {
             uint32_t cnt = std::min(g0, U(0));
             if ((rc = need(ctx, "triangleShadowTrace shadow", BUF(1), (uint64_t)cnt * kRayBytes))) return rc;
             if ((rc = check_grid(ctx, "triangleShadowTrace grid", BUF(3), U(5), BUF(2), 48, nullptr, nullptr))) return rc;
-            pt::launch_anyhit(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->ptr, BUF(3)->ptr, V(4), U(5), g0);
+            if ((rc = ensure_prepared(ctx, BUF(2), BUF(3)->off_last))) return rc;
+            pt::launch_anyhit(st, pt::KIND_TRIANGLES, U(0), BUF(1)->ptr, BUF(2)->prep, BUF(3)->ptr, V(4), U(5), exit_is_far_face(V(4), U(5)), g0);
             break;
         }
         case K_sceneRender: {
@@ -693,7 +710,7 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     memcpy(o->bound, g->bounds, sizeof o->bound);
     o->n = g->n_slabs;
     o->mesh_matid = g->mesh_matid;
-    o->exit_is_far_face = 0;
+    o->exit_is_far_face = exit_is_far_face(g->bounds, g->n_slabs);
     o->fast_ok = 1;
     for (int k = 0; k < 8; ++k) {
         if ((k & 3) == 3) continue;
@@ -701,18 +718,6 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
         if (!(a == 0.0f || (a >= 9.3132257e-10f && a <= 1048576.0f))) o->fast_ok = 0;
     }
     if (tri && !g->prims->prep_sane) o->fast_ok = 0;
-    if (g->n_slabs == 1) {
-        // A10 code.cl:699-707 with n = 1: x_next = pmin + (0 + (d>=0)) * ((pmax-pmin)/1).  When that reproduces pmax / pmin
-        // bit for bit, t_next is the very quotient interAABB already formed for the far slab plane.
-        bool exact = true;
-        for (int k = 0; k < 3; ++k) {
-            volatile float lo = g->bounds[k], hi = g->bounds[4 + k];
-            volatile float delta = (hi - lo) / 1.0f;
-            volatile float up = lo + 1.0f * delta, dn = lo + 0.0f * delta;
-            exact = exact && (up == hi) && (dn == lo) && (up == up);
-        }
-        o->exit_is_far_face = exact ? 1u : 0u;
-    }
     return MIRT_OK;
 }
 

@@ -1,6 +1,7 @@
-// pt_device.hpp -- device building blocks of the Assign10 path (gfx950).
+// pt_device.hpp -- device building blocks of the Assign10 path (gfx950): vectors, layouts, RNG, camera, ray/box, the DDA
+// axis set-up, lights, shading and bounce sampling.  Primitive tests and grid traversal live in pt_trace.hpp.
 //
-// One source of truth for the geometry used by both kernel families:
+// Shared by both kernel families:
 //   * the reference-shaped granular kernels (pt_kernels_granular.hip), drop-in
 //     for the fourteen `__kernel`s of A10 code.cl behind the WebCL-shaped API;
 //   * the fused per-ray pass kernel (pt_kernels_fused.hip).
@@ -154,45 +155,6 @@ PT_DEV void clip_to(Ray& r, const Box& b) {
     r.maxt = h.v ? h.tmax : far_;
 }
 
-// ---- primitives ------------------------------------------------------------------------
-// code.cl:199-242; .w holds r^2 (host pushes rad*rad, A10 code.js:1602)
-PT_DEV bool inter_sphere(f3 o, f3 d, float mint, float maxt, const float4 sph, float& t_out) {
-    f3 omc = sub3(o, ld3(sph));
-    float a = dot3(d, d);
-    float b = 2.0f * dot3(omc, d);
-    float c = dot3(omc, omc) - sph.w;
-    float dis = cl_mad(-4.0f * c, a, b * b);
-    if (dis < 0.0f) return false;
-    a = 1.0f / (2.0f * a);
-    dis = cl_sqrt(dis);
-    float t0 = (-b - dis) * a;
-    float t1 = (-b + dis) * a;
-    float tmin = cl_fmin(t0, t1);
-    float tmax = cl_fmax(t0, t1);
-    if (tmin >= mint && tmin <= maxt) { t_out = tmin; return true; }
-    if (tmax >= mint && tmax <= maxt) { t_out = tmax; return true; }
-    return false;
-}
-
-// code.cl:250-288: Moeller-Trumbore, single-sided (div <= 0 rejects), closed t interval
-PT_DEV bool inter_triangle(f3 o, f3 d, float mint, float maxt, f3 p0, f3 p1, f3 p2,
-                           float& t_out, float& beta_out, float& gamma_out) {
-    f3 e1 = sub3(p1, p0);
-    f3 e2 = sub3(p2, p0);
-    float div = dot3(cross3(e2, e1), d);
-    if (div <= 0) return false;
-    float idiv = 1.0f / div;
-    f3 s = sub3(o, p0);
-    float beta = dot3(cross3(s, d), e2) * idiv;
-    if (beta < 0.0f || beta > 1.0f) return false;
-    float gamma = dot3(cross3(s, e1), d) * idiv;
-    float gb = gamma + beta;
-    if (gamma < 0.0f || gb < 0.0f || gb > 1.0f) return false;
-    float t = dot3(cross3(s, e2), e1) * -idiv;
-    if (t >= mint && t <= maxt) { t_out = t; beta_out = beta; gamma_out = gamma; return true; }
-    return false;
-}
-
 // ---- 3-D uniform grid, 3-axis DDA: the traversal the reference repeats at
 // A10 code.cl:694-786, 822-919, 957-1054, 1090-1183, 1213-1310 -------------------------
 struct Axis { int slab, dslab, limit; float dt, tnext; };
@@ -213,112 +175,10 @@ PT_DEV Axis axis_setup(float o, float d, float tmin, float lo, float hi, uint32_
     return a;
 }
 
-struct Champ { uint32_t idx; float t, beta, gamma; };
-
 enum PrimKind { SPHERES = 0, TRIANGLES = 1 };
-
-// A grid of one primitive kind as the reference uploads it: cell-sorted primitives with
-// duplication, `off[n^3+1]` prefix offsets, cell c = z*n*n + y*n + x.
-struct Grid {
-    const float4* prims;      // spheres: 1 float4 (c, r^2); triangles: 3 float4 (p0,p1,p2; w unused)
-    const uint32_t* off;
-    Box bound;
-    uint32_t n;
-};
-
-// Front-to-back walk; stops at the first cell that yields a hit (code.cl:766, 899).
-// ANY: leave the cell scan at the first accepted primitive (shadow kernels, code.cl:1159, 1286).
-template <int KIND, bool ANY>
-PT_DEV Champ grid_trace(const Ray& ray, const BoxHit& bh, const Grid& g) {
-    Axis ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, g.bound.lo.x, g.bound.hi.x, g.n);
-    Axis ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, g.bound.lo.y, g.bound.hi.y, g.n);
-    Axis az = axis_setup(ray.o.z, ray.d.z, bh.tmin, g.bound.lo.z, g.bound.hi.z, g.n);
-    Champ ch;
-    ch.idx = UINT32_MAX;
-    ch.t = ray.maxt;
-    ch.beta = 0.0f;
-    ch.gamma = 0.0f;
-    float t = bh.tmin;
-    const uint32_t zs = g.n * g.n, ys = g.n;
-    for (;;) {
-        const float cmin = t;
-        const float cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
-        const uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
-        const uint32_t begin = g.off[cell], end = g.off[cell + 1];
-        for (uint32_t i = begin; i < end; ++i) {
-            float ti, b = 0.0f, gm = 0.0f;
-            bool hit;
-            if (KIND == SPHERES) {
-                hit = inter_sphere(ray.o, ray.d, cmin, cmax, g.prims[i], ti);
-            } else {
-                const float4* tp = g.prims + 3u * (size_t)i;
-                hit = inter_triangle(ray.o, ray.d, cmin, cmax, ld3(tp[0]), ld3(tp[1]), ld3(tp[2]), ti, b, gm);
-            }
-            if (hit && ti < ch.t) {
-                ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm;
-                if (ANY) break;
-            }
-        }
-        if (ch.idx != UINT32_MAX) break;
-        t = cmax;
-        if (t == ax.tnext) {
-            ax.tnext += ax.dt;
-            if (t >= bh.tmax) break;
-            ax.slab += ax.dslab;
-            if (ax.slab == ax.limit) break;
-        } else if (t == ay.tnext) {
-            ay.tnext += ay.dt;
-            if (t >= bh.tmax) break;
-            ay.slab += ay.dslab;
-            if (ay.slab == ay.limit) break;
-        } else {
-            az.tnext += az.dt;
-            if (t >= bh.tmax) break;
-            az.slab += az.dslab;
-            if (az.slab == az.limit) break;
-        }
-    }
-    return ch;
-}
 
 // A path vertex ("point of intersection"), code.cl:57-62
 struct Poi { f3 p, n, atte; int32_t matId; };
-
-// closest hit of one primitive set, z-buffered through ray.maxt (code.cl:675-800, 802-935,
-// 937-1070).  Writes p, normal, matId on a hit -- never atte (SURVEY 8a hazard 2); on a miss
-// the previous vertex stays live (hazard 3).
-template <int KIND>
-PT_DEV bool closest_hit(Ray& ray, Poi& poi, const Grid& g, const float4* normals,
-                        const uint32_t* matid, uint32_t mesh_matid) {
-    if (ray.mint == ray.maxt) return false;
-    BoxHit bh = inter_aabb(ray, g.bound);
-    if (!bh.v) return false;
-    Champ ch = grid_trace<KIND, false>(ray, bh, g);
-    if (ch.idx == UINT32_MAX) return false;
-    ray.maxt = ch.t;
-    poi.p = add3(ray.o, scl3(ch.t, ray.d));
-    if (KIND == SPHERES) {
-        poi.n = norm3(sub3(poi.p, ld3(g.prims[ch.idx])));
-    } else {
-        const float4* nn = normals + 3u * (size_t)ch.idx;
-        float w = 1.0f - ch.beta - ch.gamma;                         // code.cl:409-411
-        poi.n = norm3(add3(add3(scl3(w, ld3(nn[0])), scl3(ch.beta, ld3(nn[1]))), scl3(ch.gamma, ld3(nn[2]))));
-    }
-    poi.matId = (int32_t)(matid ? matid[ch.idx] : mesh_matid);
-    return true;
-}
-
-// any-hit of one primitive set for a shadow ray (code.cl:1073-1193, 1195-1321):
-// blocked -> mint = maxt = t (the "dead ray" mark the next kernels and sceneRender test).
-template <int KIND>
-PT_DEV void any_hit(Ray& sh, const Grid& g) {
-    if (sh.mint == sh.maxt) return;
-    BoxHit bh = inter_aabb(sh, g.bound);
-    if (!bh.v) return;
-    Champ ch = grid_trace<KIND, true>(sh, bh, g);
-    sh.maxt = ch.t;
-    if (ch.idx != UINT32_MAX) sh.mint = ch.t;
-}
 
 // ---- lights ------------------------------------------------------------------------------
 // code.cl:391-403 + 600-629.  Returns true when the disk emitter is seen before the surface.

@@ -4,8 +4,7 @@
 // (include/mirt.h).  One work-item per ray (or per pixel for initTrace / copyToPixel).
 // These are HBM-bound by construction (every stage round-trips the ray state through
 // memory, ~4.2 KB/sample on cornell.xml); the fast path is pt_kernels_fused.hip.
-#include "pt_device.hpp"
-#include "pt_launch.hpp"
+#include "pt_trace.hpp"
 
 namespace pt {
 
@@ -148,39 +147,58 @@ __global__ void __launch_bounds__(256) k_initShadowTrace(RayAoS* shadow, const P
     store_ray(&shadow[id], r);
 }
 
-// code.cl:675-800 (spheres), 802-935 (triangles, per-primitive material), 937-1070 (mesh,
-// one material): one template, three instantiations.
+// code.cl:675-800 (spheres), 802-935 (triangles, per-primitive material), 937-1070 (mesh, one material): one template,
+// three instantiations.  The traversal is pt_trace.hpp's (prepared triangles, wave-uniform loop for single-cell grids).
+PT_DEV GridArgs mk_set(const float4* prims, const uint32_t* off, const Box8& b, uint32_t n, uint32_t exit_far) {
+    GridArgs S;
+    S.prims = prims; S.normals = nullptr; S.matid = nullptr; S.off = off;
+    for (int i = 0; i < 8; ++i) S.bound[i] = b.v[i];
+    S.n = n; S.mesh_matid = 0; S.kind = 0; S.fast_ok = 0; S.exit_is_far_face = exit_far;
+    return S;
+}
 template <int KIND>
 __global__ void __launch_bounds__(256) k_closest(uint32_t total, PoiAoS* pois, RayAoS* rays, const float4* prims,
                                                   const float4* normals, const uint32_t* matid, uint32_t mesh_matid,
-                                                  const uint32_t* off, Box8 bound8, uint32_t n, uint32_t gsz) {
+                                                  const uint32_t* off, Box8 bound8, uint32_t n, uint32_t exit_far, uint32_t gsz) {
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= gsz || id >= total) return;
     Ray ray = load_ray(&rays[id]);
-    Grid g;
-    g.prims = prims; g.off = off; g.bound = mk_box(bound8); g.n = n;
-    Poi poi;
-    if (!closest_hit<KIND>(ray, poi, g, normals, matid, mesh_matid)) return;
-    rays[id].maxt = ray.maxt;
+    if (ray.mint == ray.maxt) return;
+    BoxHit bh = inter_aabb(ray, mk_box(bound8));
+    if (!bh.v) return;
+    Hit ch = trace_set<KIND, false>(ray, bh, mk_set(prims, off, bound8, n, exit_far));
+    if (ch.idx == UINT32_MAX) return;
+    rays[id].maxt = ch.t;
+    // p, normal, matId -- never atte (SURVEY 8a hazard 2); on a miss the previous vertex stays live (hazard 3)
+    f3 p = add3(ray.o, scl3(ch.t, ray.d));
+    f3 nrm;
+    if (KIND == SPHERES) {
+        nrm = norm3(sub3(p, ld3(prims[ch.idx])));
+    } else {
+        const float4* nn = normals + 3u * (size_t)ch.idx;
+        float w = 1.0f - ch.beta - ch.gamma;                         // code.cl:409-411
+        nrm = norm3(add3(add3(scl3(w, ld3(nn[0])), scl3(ch.beta, ld3(nn[1]))), scl3(ch.gamma, ld3(nn[2]))));
+    }
     PoiAoS* pp = &pois[id];
     float4* q = reinterpret_cast<float4*>(pp);
-    q[0] = make_float4(poi.p.x, poi.p.y, poi.p.z, 0.0f);
-    q[1] = make_float4(poi.n.x, poi.n.y, poi.n.z, 0.0f);
-    pp->matId = poi.matId;
+    q[0] = make_float4(p.x, p.y, p.z, 0.0f);
+    q[1] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+    pp->matId = (int32_t)(matid ? matid[ch.idx] : mesh_matid);
 }
 
-// code.cl:1073-1193, 1195-1321
+// code.cl:1073-1193, 1195-1321: blocked -> mint = maxt = t (the "dead ray" mark the next kernels and sceneRender test)
 template <int KIND>
 __global__ void __launch_bounds__(256) k_anyhit(uint32_t total, RayAoS* shadow, const float4* prims, const uint32_t* off,
-                                                 Box8 bound8, uint32_t n, uint32_t gsz) {
+                                                 Box8 bound8, uint32_t n, uint32_t exit_far, uint32_t gsz) {
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= gsz || id >= total) return;
     Ray sh = load_ray(&shadow[id]);
     if (sh.mint == sh.maxt) return;
-    Grid g;
-    g.prims = prims; g.off = off; g.bound = mk_box(bound8); g.n = n;
-    any_hit<KIND>(sh, g);
-    *reinterpret_cast<float2*>(reinterpret_cast<float4*>(&shadow[id]) + 2) = make_float2(sh.mint, sh.maxt);
+    BoxHit bh = inter_aabb(sh, mk_box(bound8));
+    if (!bh.v) return;
+    Hit ch = trace_set<KIND, true>(sh, bh, mk_set(prims, off, bound8, n, exit_far));
+    const float mint = (ch.idx != UINT32_MAX) ? ch.t : sh.mint;
+    *reinterpret_cast<float2*>(reinterpret_cast<float4*>(&shadow[id]) + 2) = make_float2(mint, ch.t);
 }
 
 // code.cl:1323-1364.  `nmat` guards the material fetch: an out-of-range id (undefined
@@ -384,22 +402,22 @@ void launch_initShadowTrace(hipStream_t s, void* shadow, const void* pois, uint3
     hipLaunchKernelGGL(k_initShadowTrace, grid1(gsz), dim3(256), 0, s, (RayAoS*)shadow, (const PoiAoS*)pois, total, mk16(light), (int32_t*)seeds, gsz);
 }
 void launch_closest(hipStream_t s, int kind, uint32_t total, void* pois, void* rays, const void* prims, const void* normals,
-                    const void* matid, uint32_t mesh_matid, const void* off, const float* bound, uint32_t n, uint32_t gsz) {
+                    const void* matid, uint32_t mesh_matid, const void* off, const float* bound, uint32_t n, uint32_t exit_far, uint32_t gsz) {
     if (!gsz) return;
     if (kind == SPHERES)
         hipLaunchKernelGGL(k_closest<SPHERES>, grid1(gsz), dim3(256), 0, s, total, (PoiAoS*)pois, (RayAoS*)rays, (const float4*)prims,
-                           (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, gsz);
+                           (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, exit_far, gsz);
     else
         hipLaunchKernelGGL(k_closest<TRIANGLES>, grid1(gsz), dim3(256), 0, s, total, (PoiAoS*)pois, (RayAoS*)rays, (const float4*)prims,
-                           (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, gsz);
+                           (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, exit_far, gsz);
 }
 void launch_anyhit(hipStream_t s, int kind, uint32_t total, void* shadow, const void* prims, const void* off, const float* bound,
-                   uint32_t n, uint32_t gsz) {
+                   uint32_t n, uint32_t exit_far, uint32_t gsz) {
     if (!gsz) return;
     if (kind == SPHERES)
-        hipLaunchKernelGGL(k_anyhit<SPHERES>, grid1(gsz), dim3(256), 0, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, gsz);
+        hipLaunchKernelGGL(k_anyhit<SPHERES>, grid1(gsz), dim3(256), 0, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, exit_far, gsz);
     else
-        hipLaunchKernelGGL(k_anyhit<TRIANGLES>, grid1(gsz), dim3(256), 0, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, gsz);
+        hipLaunchKernelGGL(k_anyhit<TRIANGLES>, grid1(gsz), dim3(256), 0, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, exit_far, gsz);
 }
 void launch_sceneRender(hipStream_t s, void* acu, void* pois, const void* shadow, const void* material, uint32_t nmat,
                         const float* light, uint32_t total, uint32_t gsz) {

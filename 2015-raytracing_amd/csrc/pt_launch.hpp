@@ -19,9 +19,9 @@ void launch_bouncePaths(hipStream_t s, const void* pois, void* rays, void* seeds
 void launch_lightRender(hipStream_t s, void* pois, void* rays, void* acu, const float* light, uint32_t total, uint32_t gsz);
 void launch_initShadowTrace(hipStream_t s, void* shadow, const void* pois, uint32_t total, const float* light, void* seeds, uint32_t gsz);
 void launch_closest(hipStream_t s, int kind, uint32_t total, void* pois, void* rays, const void* prims, const void* normals,
-                    const void* matid, uint32_t mesh_matid, const void* off, const float* bound, uint32_t n, uint32_t gsz);
+                    const void* matid, uint32_t mesh_matid, const void* off, const float* bound, uint32_t n, uint32_t exit_far, uint32_t gsz);
 void launch_anyhit(hipStream_t s, int kind, uint32_t total, void* shadow, const void* prims, const void* off, const float* bound,
-                   uint32_t n, uint32_t gsz);
+                   uint32_t n, uint32_t exit_far, uint32_t gsz);
 void launch_sceneRender(hipStream_t s, void* acu, void* pois, const void* shadow, const void* material, uint32_t nmat,
                         const float* light, uint32_t total, uint32_t gsz);
 void launch_copyToPixel(hipStream_t s, void* pixel, const void* acu, float m, uint32_t pixels, uint32_t rpp, uint32_t gsz, void* radiance);

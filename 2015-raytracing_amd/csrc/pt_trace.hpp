@@ -17,7 +17,7 @@ namespace pt {
 struct Hit { uint32_t idx; float t, beta, gamma; };
 
 // Moeller-Trumbore on a prepared triangle; same operations, same order and the same
-// accept/reject predicates as inter_triangle (pt_device.hpp), written without early exits:
+// accept/reject predicates as the reference's interTriangle (A10 code.cl:250-288), written without early exits:
 // in a wave-uniform loop the 64 lanes leave at different tests anyway.
 // TRI_A10: closed t interval, no gamma > 1 test (A10 code.cl:273, 280)
 // TRI_A07: open t interval, no gamma > 1 test   (A07 code.cl:188, 195)
