@@ -49,7 +49,7 @@ struct mirt_ctx {
     void* defer_list = nullptr;
     size_t defer_list_bytes = 0;
     uint64_t last_deferred = 0;   // samples the last mirt_render_pass handed to the exact kernel
-    int force_exact = 1;          // mirt_ctx_set_exact_only: the optimistic two-kernel pass is opt-in (it measured within 1 % of this)
+    int force_exact = 0;          // mirt_ctx_set_exact_only: 1 = skip the optimistic kernel, run every sample through the exact one
     bool profiling = false;       // per-kernel events inside mirt_render_pass
     hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
     bool pe_valid = false;
@@ -998,7 +998,8 @@ int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, 
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_divcheck: unknown context");
     int rc = need(ctx, "mirt_debug_divcheck out", out16, 16 * 8);
     if (rc) return rc;
-    if (mode < 0 || mode > 3) return fail(ctx, MIRT_E_ARG, "mirt_debug_divcheck: mode is 0..3");
+    if (mode < 0 || mode > 4) return fail(ctx, MIRT_E_ARG, "mirt_debug_divcheck: mode is 0..4");
+    if (mode == 4 && (seed > (1u << 23) || count > (1u << 23) - seed)) return fail(ctx, MIRT_E_ARG, "mirt_debug_divcheck: mode 4 walks denominators [seed, seed+count) within 2^23 mantissas");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(out16->ptr, 0, 16 * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync((char*)out16->ptr + 80, 0xFF, 8, ctx->stream));   // out[10]: running minimum

@@ -151,14 +151,14 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 }
 
 #ifndef PT_FUSED_WAVES
-#define PT_FUSED_WAVES 6   // waves per SIMD the register allocator must leave room for (A/B: 4 -> 213 ms, 5 -> 205, 6 -> 200, 8 -> 243 with spills)
+#define PT_FUSED_WAVES 6   // waves per SIMD the register allocator must leave room for (A/B without SLP packing: 5 -> 182.8 ms, 6 -> 178.3, 7 -> 181.0, 8 -> 192.1)
 #endif
 // FAST = true : the optimistic kernel.  Every division in the traversal is one of the exact cheap forms; a sample whose rays
 //               ever leave the guard window sets its bit in `defer_mask` and leaves seeds[]/acu[] untouched.
 // FAST = false: the exact kernel (true divisions).  With `list` it recomputes the deferred samples; with list == nullptr it
 //               is the whole pass (geometry outside the guard, or PT_EXACT_FAST_DIV = 0).
 #ifndef PT_FUSED_WAVES_FAST
-#define PT_FUSED_WAVES_FAST 5   // the optimistic kernel: 95 VGPRs, 12 B scratch (A/B: 6 -> 200.4 ms, 5 -> 195.7, 4 -> 210.4; exact kernel 197.5)
+#define PT_FUSED_WAVES_FAST 6   // the optimistic kernel: 80 VGPRs, 44 B scratch (A/B without SLP packing: 5 -> 168.9 ms, 6 -> 161.6, 7 -> 162.2, 8 -> 178.4; exact kernel 178.8)
 #endif
 template <bool FAST>
 __global__ void __launch_bounds__(256, FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count) {

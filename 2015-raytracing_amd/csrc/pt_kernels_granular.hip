@@ -324,6 +324,22 @@ __global__ void __launch_bounds__(256) k_divCheck(int mode, uint64_t seed, uint6
         if (m1) { atomicAdd(&out[1], m1); atomicMin(&out[10], lo); atomicMax(&out[11], hi); }
         return;
     }
+    if (mode == 4) {
+        // EVERY mantissa pair: d = 1.dm, n = 1.nm, dm in [seed, seed + count), nm in [0, 2^23).  Powers of two scale every
+        // step of div_exact3 exactly while nothing leaves the normal range (the windows guarantee that) and rcp_refined is
+        // RN(1/d) for every d in its window (mode 3), so one binade pair stands for all of them; signs are symmetric.
+        // out[3] = mismatches, out[6]/out[7] = first mismatching (n, d)
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (count << 23); i += stride) {
+            const float d = __uint_as_float(0x3F800000u | (uint32_t)(seed + (i >> 23)));
+            const float n = __uint_as_float(0x3F800000u | (uint32_t)(i & 0x7FFFFFu));
+            if (__float_as_uint(div_exact3(n, d, rcp_refined(d))) != __float_as_uint(n / d)) {
+                if (!m3 && !atomicAdd(&out[9], 1ull)) { out[6] = __float_as_uint(n); out[7] = __float_as_uint(d); }
+                ++m3;
+            }
+        }
+        if (m3) atomicAdd(&out[3], m3);
+        return;
+    }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         uint64_t h = (i + seed) * 0x9E3779B97F4A7C15ull;
         h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;

@@ -121,6 +121,8 @@ def main():
     ctx = mirt.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_profiling(True)
+    if os.environ.get("MIRT_EXACT_ONLY") == "1":   # A/B knob: the single exact kernel instead of the default optimistic pair
+        ctx.set_exact_only(True)
     fr = render.FusedRenderer(ctx, sc, row0=row0, nrows=nrows, want_radiance=True)
     # the RGBA8 tile lives in a torch tensor so RCCL can move it
     tile = torch.zeros(max_rows * sc.width * 4, dtype=torch.uint8, device="cuda")

@@ -163,10 +163,12 @@ typedef struct mirt_pass_desc {
 } mirt_pass_desc;
 
 MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
-/* Two ways to run the pass, identical results.  Default (exact only): one kernel whose every division is the compiler's
- * correctly rounded expansion.  mirt_ctx_set_exact_only(ctx, 0) selects the optimistic pair: a kernel whose divisions are
- * 3-operation forms that are bit-exact inside a guard window, plus the exact kernel re-running the samples whose rays left the
- * window (NaN rays, axis-parallel directions, ...).  mirt_pass_deferred: how many samples the last pass re-ran that way. */
+/* Two ways to run the pass, identical results.  Default: the optimistic pair -- a kernel whose divisions are 3-operation
+ * forms proven bit-exact inside a guard window (exhaustively, on the device: profiles/r1_divcheck_exhaustive.txt), plus the
+ * exact kernel re-running the samples whose rays left the window (NaN rays, axis-parallel directions, ...); it needs every
+ * grid to pass the geometry-side window check, otherwise the pass silently is the exact one.  mirt_ctx_set_exact_only(ctx, 1):
+ * one kernel whose every division is the compiler's correctly rounded expansion.  mirt_pass_deferred: how many samples the
+ * last pass re-ran through the exact kernel. */
 MIRT_API int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples);
 MIRT_API int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on);
 
@@ -206,7 +208,9 @@ MIRT_API int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total
 MIRT_API int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n);
 
 /* counts mismatches between the shared-reciprocal division forms of pt_numerics.hpp and the compiler's correctly
- * rounded division over `count` generated (n, d) pairs; `out16` receives 16 uint64 (see k_divCheck) */
+ * rounded division over `count` generated (n, d) pairs; `out16` receives 16 uint64 (see k_divCheck).
+ * mode 0/1/2: random pairs inside the windows; 3: all 2^32 denominators of the reciprocal; 4: every numerator mantissa
+ * against the `count` denominator mantissas starting at `seed` (2^23 launches' worth covers all 2^46 pairs) */
 MIRT_API int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16);
 
 /* ---- measurement: HIP events on the context's stream ---------------------------------- */

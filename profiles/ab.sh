@@ -6,3 +6,7 @@ for lib in ab/libmirt_*.so; do
   r=$(MIRT_LIB_PATH="$PWD/$lib" timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu 2>/dev/null)
   echo "$(basename $lib) $(echo "$r" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["roofline"]["launch_ms"], d["value"])' 2>/dev/null || echo FAILED)"
 done
+if [ "${AB_EXACT_ONLY:-0}" = 1 ]; then for lib in ab/libmirt_*.so; do
+  r=$(MIRT_EXACT_ONLY=1 MIRT_LIB_PATH="$PWD/$lib" timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu 2>/dev/null)
+  echo "exact_only $(basename $lib) $(echo "$r" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["roofline"]["launch_ms"], d["value"])' 2>/dev/null || echo FAILED)"
+done; fi

@@ -117,3 +117,7 @@ def test_cheap_exact_division_forms(ctx):
         assert int(r[1]) == 0 and int(r[2]) == 0
         if mode == 2:
             assert int(r[0]) == 0 and int(r[3]) == 0       # without +-0 numerators even the bare forms agree
+    # a slice of the exhaustive mantissa-pair sweep (all 2^46 pairs: profiles/divcheck.py --exhaustive, result under profiles/)
+    for first in (0, 0x400000, 0x7FFF00):
+        r = ctx.divcheck(4, first, 256)
+        assert int(r[3]) == 0, f"div_exact3(1.nm, 1.dm) differs for dm near {first:#x}: n,d bits {int(r[6]):#x},{int(r[7]):#x}"
