@@ -40,16 +40,17 @@ PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const f
     float gamma = dot3(cross3(s, e1), d) * idiv;
     float gb = gamma + beta;
     float t = dot3(cross3(s, e2), e1) * -idiv;
-    bool ok = !(div <= 0);
-    ok = ok && !(beta < 0.0f || beta > 1.0f);
-    if (RULE == TRI_A04) ok = ok && !(gamma < 0.0f || gamma > 1.0f || gb < 0.0f || gb > 1.0f);
-    else ok = ok && !(gamma < 0.0f || gb < 0.0f || gb > 1.0f);
-    if (RULE == TRI_A10) ok = ok && (t >= cmin && t <= cmax);
-    else ok = ok && (t > cmin && t < cmax);
+    // one mask per predicate, combined with & (not &&): no exec-mask branches around two-instruction tails
+    int ok = !(div <= 0);
+    ok &= !(beta < 0.0f) & !(beta > 1.0f);
+    if (RULE == TRI_A04) ok &= !(gamma < 0.0f) & !(gamma > 1.0f) & !(gb < 0.0f) & !(gb > 1.0f);
+    else ok &= !(gamma < 0.0f) & !(gb < 0.0f) & !(gb > 1.0f);
+    if (RULE == TRI_A10) ok &= (t >= cmin) & (t <= cmax);
+    else ok &= (t > cmin) & (t < cmax);
     t_out = t;
     beta_out = beta;
     gamma_out = gamma;
-    return ok;
+    return ok != 0;
 }
 
 // Ray-side guard of the exact cheap divisions (pt_numerics.hpp "exact division, cheaper"): |d_k| in [2^-40, 2^40] and o_k zero or
@@ -110,10 +111,10 @@ PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, co
     float t1 = (-b + sq) * sr.inv2a;
     float tmin = cl_fmin(t0, t1);
     float tmax = cl_fmax(t0, t1);
-    const bool in0 = (tmin >= cmin && tmin <= cmax);
-    const bool in1 = (tmax >= cmin && tmax <= cmax);
+    const int in0 = (tmin >= cmin) & (tmin <= cmax);
+    const int in1 = (tmax >= cmin) & (tmax <= cmax);
     t_out = in0 ? tmin : tmax;
-    return !(dis < 0.0f) && (in0 || in1);
+    return (!(dis < 0.0f) & (in0 | in1)) != 0;
 }
 
 // One primitive set.  KIND / ANY as in pt_device.hpp.  n == 1: a single cell, every lane walks
@@ -154,16 +155,20 @@ PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
 #if PT_UNROLL_UNIFORM > 1
 #pragma unroll PT_UNROLL_UNIFORM
 #endif
-        for (uint32_t i = begin; i < end; ++i) {
+        const float4* __restrict__ p = prims + (size_t)begin * (KIND == SPHERES ? 1u : 3u);   // one running pointer: immediate-offset scalar loads
+        for (uint32_t i = begin; i < end; ++i, p += (KIND == SPHERES ? 1 : 3)) {
             float ti, b = 0.0f, gm = 0.0f;
             bool hit;
             if (KIND == SPHERES) {
-                hit = sph_test(ray.o, ray.d, sr, cmin, cmax, prims[i], ti);
+                hit = sph_test(ray.o, ray.d, sr, cmin, cmax, p[0], ti);
             } else {
-                hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, prims[3u * i], prims[3u * i + 1], prims[3u * i + 2], ti, b, gm);
+                hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, gm);
             }
-            const bool better = !done && hit && ti < ch.t;
-            if (better) { ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm; }
+            const bool better = (int)!done & (int)hit & (int)(ti < ch.t);
+            ch.t = better ? ti : ch.t;          // selects, not a branch: some lane of an incoherent wave almost always hits
+            ch.idx = better ? i : ch.idx;
+            ch.beta = better ? b : ch.beta;
+            ch.gamma = better ? gm : ch.gamma;
             if (ANY) {
                 done = done || better;
                 if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every lane of the wave is blocked
