@@ -86,7 +86,7 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
         BoxHit bh = inter_aabb_t<FAST>(ray, set_box(S));
         if (!bh.v) continue;
         if (S.kind == KIND_SPHERES) {
-            Hit ch = trace_set<SPHERES, false, TRI_A10, FAST>(ray, bh, S);
+            Hit ch = trace_set<SPHERES, false, TRI_A10, FAST>(ray, bh, S, defer);
             if (ch.idx == UINT32_MAX) continue;
             ray.maxt = ch.t;
             poi.p = add3(ray.o, scl3(ch.t, ray.d));
@@ -96,7 +96,7 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
             park.put_pn(poi);
 #endif
         } else {
-            Hit ch = trace_set<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S);
+            Hit ch = trace_set<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S, defer);
             if (ch.idx == UINT32_MAX) continue;
             ray.maxt = ch.t;
             poi.p = add3(ray.o, scl3(ch.t, ray.d));
@@ -129,7 +129,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             if (sh.mint == sh.maxt) continue;
             BoxHit bh = inter_aabb_t<FAST>(sh, set_box(S));
             if (!bh.v) continue;
-            Hit ch = (S.kind == KIND_SPHERES) ? trace_set<SPHERES, true, TRI_A10, FAST>(sh, bh, S) : trace_set<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S);
+            Hit ch = (S.kind == KIND_SPHERES) ? trace_set<SPHERES, true, TRI_A10, FAST>(sh, bh, S, defer) : trace_set<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S, defer);
             sh.maxt = ch.t;
             if (ch.idx != UINT32_MAX) sh.mint = ch.t;
         }

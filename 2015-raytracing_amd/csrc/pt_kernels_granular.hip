@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(256) k_closest(uint32_t total, PoiAoS* pois, R
     if (ray.mint == ray.maxt) return;
     BoxHit bh = inter_aabb(ray, mk_box(bound8));
     if (!bh.v) return;
-    Hit ch = trace_set<KIND, false>(ray, bh, mk_set(prims, off, bound8, n, exit_far));
+    bool unused = false;
+    Hit ch = trace_set<KIND, false>(ray, bh, mk_set(prims, off, bound8, n, exit_far), unused);
     if (ch.idx == UINT32_MAX) return;
     rays[id].maxt = ch.t;
     // p, normal, matId -- never atte (SURVEY 8a hazard 2); on a miss the previous vertex stays live (hazard 3)
@@ -196,7 +197,8 @@ __global__ void __launch_bounds__(256) k_anyhit(uint32_t total, RayAoS* shadow, 
     if (sh.mint == sh.maxt) return;
     BoxHit bh = inter_aabb(sh, mk_box(bound8));
     if (!bh.v) return;
-    Hit ch = trace_set<KIND, true>(sh, bh, mk_set(prims, off, bound8, n, exit_far));
+    bool unused = false;
+    Hit ch = trace_set<KIND, true>(sh, bh, mk_set(prims, off, bound8, n, exit_far), unused);
     const float mint = (ch.idx != UINT32_MAX) ? ch.t : sh.mint;
     *reinterpret_cast<float2*>(reinterpret_cast<float4*>(&shadow[id]) + 2) = make_float2(mint, ch.t);
 }

@@ -117,10 +117,38 @@ PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, co
     return (!(dis < 0.0f) & (in0 | in1)) != 0;
 }
 
+// axis_setup (pt_device.hpp) with the optimistic kernel's divisions: every quotient is div_exact3 on a refined reciprocal.  The
+// denominators are the ray direction (ray_guard), the slab count and the slab width; numerators and the slab width are checked
+// here, per lane, and a lane outside the windows marks its sample for the exact kernel.
+PT_DEV bool num_window(float v) { const float a = __builtin_fabsf(v); return v == 0.0f || (a >= 8.6736174e-19f && a <= 1.1529215e18f); }   // 0 | 2^-60 .. 2^60
+PT_DEV bool den_window(float v) { const float a = __builtin_fabsf(v); return a >= 9.094947e-13f && a <= 1.0995116e12f; }                    // 2^-40 .. 2^40
+template <bool FAST>
+PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint32_t n, bool& defer) {
+    if (!FAST) return axis_setup(o, d, tmin, lo, hi, n);
+    Axis a;
+    const float x = o + tmin * d;
+    const float fn = (float)n, span = hi - lo;
+    const float delta = div_exact3(span, fn, rcp_refined(fn));
+    const float num0 = x - lo;
+    a.slab = f2i(div_exact3(num0, delta, rcp_refined(delta)));
+    if (a.slab < 0) a.slab = 0;
+    if ((uint32_t)a.slab >= n) a.slab = (int)(n - 1u);
+    const bool fwd = d >= 0;
+    a.dslab = fwd ? 1 : -1;
+    a.limit = fwd ? (int)n : -1;
+    const float rd = rcp_refined(d);
+    a.dt = div_exact3(delta, cl_fabs(d), cl_fabs(rd));   // rcp_refined is odd in d: every step is sign-symmetric under RNE
+    const float xnext = lo + (float)(a.slab + (fwd ? 1 : 0)) * delta;
+    const float num1 = xnext - o;
+    a.tnext = div_exact3(num1, d, rd);
+    defer = defer || !(num_window(span) && num_window(num0) && den_window(delta) && num_window(num1));
+    return a;
+}
+
 // One primitive set.  KIND / ANY as in pt_device.hpp.  n == 1: a single cell, every lane walks
 // the same list -> wave-uniform loop, scalar loads.  n > 1: per-lane 3-axis DDA.
 template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false>
-PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
+PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer) {
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
     Hit ch;
@@ -177,47 +205,62 @@ PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         return ch;
     }
 
-    Axis ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n);
-    Axis ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n);
-    Axis az = axis_setup(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n);
-    float t = bh.tmin;
+    Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, defer);
+    Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, defer);
+    Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, defer);
+    // The reference walks cell by cell and, inside a cell, primitive by primitive (two nested loops per work-item).  Run that way
+    // on a 64-lane wave every outer iteration costs the LONGEST list any lane holds.  Same per-lane sequence, re-phased:
+    //   phase A: every lane whose list is exhausted closes its cell (stop on a hit, else step) and opens the next one -- cheap
+    //            iterations, repeated until each live lane holds a primitive or has left the grid;
+    //   phase B: every live lane tests ONE primitive.
+    // A lane's tests, their order and their [cmin, cmax] windows are exactly those of the nested loops.
     const uint32_t zs = S.n * S.n, ys = S.n;
+    float t = bh.tmin, cmin = 0.0f, cmax = 0.0f;
+    uint32_t i = 0, end = 0;
+    bool opened = false;
     for (;;) {
-        const float cmin = t;
-        const float cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
-        const uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
-        const uint32_t begin = off[cell], end = off[cell + 1];
-        for (uint32_t i = begin; i < end; ++i) {
-            float ti, b = 0.0f, gm = 0.0f;
-            bool hit;
-            if (KIND == SPHERES) {
-                hit = sph_test(ray.o, ray.d, sr, cmin, cmax, prims[i], ti);
-            } else {
-                hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, prims[3u * i], prims[3u * i + 1], prims[3u * i + 2], ti, b, gm);
+        bool alive = true;
+        while (i == end) {
+            if (opened) {
+                if (ch.idx != UINT32_MAX) { alive = false; break; }
+                t = cmax;
+                if (t == ax.tnext) {
+                    ax.tnext += ax.dt;
+                    ax.slab += ax.dslab;
+                    if (t >= bh.tmax || ax.slab == ax.limit) { alive = false; break; }
+                } else if (t == ay.tnext) {
+                    ay.tnext += ay.dt;
+                    ay.slab += ay.dslab;
+                    if (t >= bh.tmax || ay.slab == ay.limit) { alive = false; break; }
+                } else {
+                    az.tnext += az.dt;
+                    az.slab += az.dslab;
+                    if (t >= bh.tmax || az.slab == az.limit) { alive = false; break; }
+                }
             }
-            if (hit && ti < ch.t) {
-                ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = gm;
-                if (ANY) break;
-            }
+            opened = true;
+            cmin = t;
+            cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+            const uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
+            i = off[cell];
+            end = off[cell + 1];
         }
-        if (ch.idx != UINT32_MAX) break;
-        t = cmax;
-        if (t == ax.tnext) {
-            ax.tnext += ax.dt;
-            if (t >= bh.tmax) break;
-            ax.slab += ax.dslab;
-            if (ax.slab == ax.limit) break;
-        } else if (t == ay.tnext) {
-            ay.tnext += ay.dt;
-            if (t >= bh.tmax) break;
-            ay.slab += ay.dslab;
-            if (ay.slab == ay.limit) break;
+        if (!alive) break;
+        float ti, b = 0.0f, gm = 0.0f;
+        bool hit;
+        if (KIND == SPHERES) {
+            hit = sph_test(ray.o, ray.d, sr, cmin, cmax, prims[i], ti);
         } else {
-            az.tnext += az.dt;
-            if (t >= bh.tmax) break;
-            az.slab += az.dslab;
-            if (az.slab == az.limit) break;
+            const float4* __restrict__ p = prims + 3u * (size_t)i;
+            hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, gm);
         }
+        const bool better = (int)hit & (int)(ti < ch.t);
+        ch.t = better ? ti : ch.t;
+        ch.idx = better ? i : ch.idx;
+        ch.beta = better ? b : ch.beta;
+        ch.gamma = better ? gm : ch.gamma;
+        ++i;
+        if (ANY && better) break;
     }
     return ch;
 }

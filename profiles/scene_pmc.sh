@@ -1,0 +1,18 @@
+#!/bin/bash
+# profiles/scene_pmc.sh <fixture-name> <tag> -- SQ counters of the fused kernel on one fixture scene at 1080p x 16 (scene_bench.py)
+set -uo pipefail
+export TMPDIR=/tmp
+export SCENES="$1"
+OUT="gpurun_out/scene_$2"; mkdir -p "$OUT"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/a" -- python3 profiles/scene_bench.py > "$OUT/a.log" 2>&1 || exit 11
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SMEM --output-format csv -d "$OUT/b" -- python3 profiles/scene_bench.py > "$OUT/b.log" 2>&1 || exit 12
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d "$OUT/c" -- python3 profiles/scene_bench.py > "$OUT/c.log" 2>&1 || echo "pass c failed (counter names?)"
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+agg=collections.defaultdict(list)
+for f in glob.glob(sys.argv[1]+'/*/*/*_counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        if 'k_fusedPass<true>' in r['Kernel_Name'] or 'k_fusedPassILb1' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+w=sum(agg['SQ_WAVES'])/len(agg['SQ_WAVES'])
+print(' '.join(f"{k.replace('SQ_','')}={sum(v)/len(v)/w:.0f}" for k,v in sorted(agg.items())))
+PY
