@@ -77,63 +77,86 @@ PT_DEV Box set_box(const GridArgs& S) {
 
 // closest hit over every set in upload order, z-buffered through ray.maxt
 // (A10 code.cl:675-800, 802-935, 937-1070; order A10 code.js:1809-1813)
-template <bool FAST>
+template <bool FAST, bool GRIDS>
 PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park, bool& defer) {
     if (FAST && !(ray.mint == ray.maxt)) defer = defer || !ray_guard(ray);   // a dead ray divides nothing
     for (uint32_t s = 0; s < A.n_sets; ++s) {
         const GridArgs& S = A.sets[s];
-        if (ray.mint == ray.maxt) continue;
-        BoxHit bh = inter_aabb_t<FAST>(ray, set_box(S));
-        if (!bh.v) continue;
+        const bool live = !(ray.mint == ray.maxt);
+        Hit ch;
+        ch.idx = UINT32_MAX;
+        if (!GRIDS || S.n == 1u) {
+            if (live) {
+                const BoxHit bh = inter_aabb_t<FAST>(ray, set_box(S));
+                if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, false, TRI_A10, FAST>(ray, bh, S) : trace_cell1<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S);
+            }
+        } else if (live) {
+            const BoxHit bh = inter_aabb_t<FAST>(ray, set_box(S));
+            if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, false, TRI_A10, FAST>(ray, bh, S, defer) : trace_dda<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S, defer);
+        }
+        if (ch.idx == UINT32_MAX) continue;
+        ray.maxt = ch.t;
+        poi.p = add3(ray.o, scl3(ch.t, ray.d));
         if (S.kind == KIND_SPHERES) {
-            Hit ch = trace_set<SPHERES, false, TRI_A10, FAST>(ray, bh, S, defer);
-            if (ch.idx == UINT32_MAX) continue;
-            ray.maxt = ch.t;
-            poi.p = add3(ray.o, scl3(ch.t, ray.d));
             poi.n = norm3(sub3(poi.p, ld3(((const float4*)S.prims)[ch.idx])));
             poi.matId = (int32_t)((const uint32_t*)S.matid)[ch.idx];
-#if PT_PARK_LDS && PT_PARK_PN
-            park.put_pn(poi);
-#endif
         } else {
-            Hit ch = trace_set<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S, defer);
-            if (ch.idx == UINT32_MAX) continue;
-            ray.maxt = ch.t;
-            poi.p = add3(ray.o, scl3(ch.t, ray.d));
             const float4* nn = (const float4*)S.normals + 3u * (size_t)ch.idx;
             float w = 1.0f - ch.beta - ch.gamma;  // code.cl:409-411
             poi.n = norm3(add3(add3(scl3(w, ld3(nn[0])), scl3(ch.beta, ld3(nn[1]))), scl3(ch.gamma, ld3(nn[2]))));
             poi.matId = (int32_t)(S.matid ? ((const uint32_t*)S.matid)[ch.idx] : S.mesh_matid);
-#if PT_PARK_LDS && PT_PARK_PN
-            park.put_pn(poi);
-#endif
         }
+#if PT_PARK_LDS && PT_PARK_PN
+        park.put_pn(poi);
+#endif
     }
 }
 
 // per light: shadow ray, any-hit over every set, shade (A10 code.js:1817-1826; code.cl:631-673,
 // 1073-1321, 1323-1364)
-template <bool FAST>
+template <bool FAST, bool GRIDS>
 PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc, const Park& park, bool& defer) {
     const float4* material = (const float4*)A.material;
     for (uint32_t l = 0; l < A.n_lights; ++l) {
         const LightArgs& L = A.lights[l];
-        if (poi.matId < 0) continue;  // initShadowTrace: a dead path draws nothing (code.cl:645-650)
+        const bool path = poi.matId >= 0;  // initShadowTrace: a dead path draws nothing (code.cl:645-650)
+        Ray sh;
+        sh.o = mk3(0.0f, 0.0f, 0.0f);
+        sh.d = mk3(0.0f, 0.0f, 0.0f);
+        sh.mint = PT_INF;
+        sh.maxt = PT_INF;
+        if (path) {
 #if PT_PARK_LDS && PT_PARK_PN
-        park.get_pn(poi);
+            park.get_pn(poi);
 #endif
-        Ray sh = shadow_ray(poi, ld3(L.shadow), ld3(L.shadow + 3), ld3(L.shadow + 6), L.shadow[9], seed);
-        if (FAST) defer = defer || !ray_guard(sh);
+            sh = shadow_ray(poi, ld3(L.shadow), ld3(L.shadow + 3), ld3(L.shadow + 6), L.shadow[9], seed);
+            if (FAST) defer = defer || !ray_guard(sh);
+        }
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
-            if (sh.mint == sh.maxt) continue;
-            BoxHit bh = inter_aabb_t<FAST>(sh, set_box(S));
-            if (!bh.v) continue;
-            Hit ch = (S.kind == KIND_SPHERES) ? trace_set<SPHERES, true, TRI_A10, FAST>(sh, bh, S, defer) : trace_set<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S, defer);
+            const bool live = path && !(sh.mint == sh.maxt);
+            Hit ch;
+            bool walked = false;
+            if (!GRIDS || S.n == 1u) {
+                if (live) {
+                    const BoxHit bh = inter_aabb_t<FAST>(sh, set_box(S));
+                    if (bh.v) {
+                        ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, true, TRI_A10, FAST>(sh, bh, S) : trace_cell1<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S);
+                        walked = true;
+                    }
+                }
+            } else if (live) {
+                const BoxHit bh = inter_aabb_t<FAST>(sh, set_box(S));
+                if (bh.v) {
+                    ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, true, TRI_A10, FAST>(sh, bh, S, defer) : trace_dda<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S, defer);
+                    walked = true;
+                }
+            }
+            if (!walked) continue;
             sh.maxt = ch.t;
             if (ch.idx != UINT32_MAX) sh.mint = ch.t;
         }
-        if ((uint32_t)poi.matId >= A.nmat) continue;  // out-of-range id: shade nothing (see k_sceneRender)
+        if (!path || (uint32_t)poi.matId >= A.nmat) continue;  // out-of-range id: shade nothing (see k_sceneRender)
         float4 c4 = material[poi.matId];
 #if PT_PARK_LDS
 #if PT_PARK_PN
@@ -160,8 +183,18 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 #ifndef PT_FUSED_WAVES_FAST
 #define PT_FUSED_WAVES_FAST 6   // the optimistic kernel: 80 VGPRs, 44 B scratch (A/B without SLP packing: 5 -> 168.9 ms, 6 -> 161.6, 7 -> 162.2, 8 -> 178.4; exact kernel 178.8)
 #endif
-template <bool FAST>
-__global__ void __launch_bounds__(256, FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count) {
+// GRIDS = false: every set is a single cell (n == 1: the reference's loose spheres and triangles, A10 code.js:399): only the
+//                wave-uniform loops are compiled in.  Without the DDA the register allocator needs 74 VGPRs and no scratch
+//                (80 + 56 B with it): 157.3 -> 152.6 ms on the headline scene.  launch_fused picks it when every set has n == 1.
+// GRIDS = true : sets with n > 1 walk their grid per lane (trace_dda).
+// Tried and dropped for GRIDS: packing the rays that hit a mesh's box across the block's four waves through LDS (one wave walks
+// 64 packed rays, three wait at a barrier).  It cuts VALU instructions 4x on those walks and was 30 % SLOWER (cornell_teapot3
+// 1080p x16: 72.2 -> 93.8 ms): the waiting waves keep their registers, so each SIMD is left with too few runnable waves.
+#ifndef PT_FUSED_WAVES_GRIDS
+#define PT_FUSED_WAVES_GRIDS 6
+#endif
+template <bool FAST, bool GRIDS>
+__global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES)) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count) {
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;
     uint64_t lid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (!FAST && list) {
@@ -233,7 +266,7 @@ __global__ void __launch_bounds__(256, FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAV
                 ray.maxt = PT_INF;
             }
         }
-        closest_all<FAST>(A, ray, poi, park, defer);
+        closest_all<FAST, GRIDS>(A, ray, poi, park, defer);
         if (seg == 0) {
             for (uint32_t l = 0; l < A.n_lights; ++l) {  // lightRender (code.cl:600-629), primary segment only
                 if (ray.mint == ray.maxt) continue;
@@ -250,7 +283,7 @@ __global__ void __launch_bounds__(256, FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAV
 #endif
             }
         }
-        direct_all<FAST>(A, poi, seed, acc, park, defer);
+        direct_all<FAST, GRIDS>(A, poi, seed, acc, park, defer);
     }
 
     if (FAST && defer) {   // hand the sample to the exact kernel: its inputs stay as they were
@@ -283,9 +316,16 @@ __global__ void __launch_bounds__(256) k_deferList(const uint32_t* mask, uint32_
 void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count) {
     const uint64_t n = list ? list_count : (uint64_t)a.nrows * a.width * a.rpp;
     if (!n) return;
+    bool grids = false;
+    for (uint32_t i = 0; i < a.n_sets; ++i) grids = grids || a.sets[i].n != 1u;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (fast) hipLaunchKernelGGL(k_fusedPass<true>, grid, dim3(256), 0, s, a, defer_mask, (const uint32_t*)nullptr, 0u);
-    else hipLaunchKernelGGL(k_fusedPass<false>, grid, dim3(256), 0, s, a, (uint32_t*)nullptr, list, list_count);
+    if (fast) {
+        if (grids) hipLaunchKernelGGL((k_fusedPass<true, true>), grid, dim3(256), 0, s, a, defer_mask, (const uint32_t*)nullptr, 0u);
+        else hipLaunchKernelGGL((k_fusedPass<true, false>), grid, dim3(256), 0, s, a, defer_mask, (const uint32_t*)nullptr, 0u);
+    } else {
+        if (grids) hipLaunchKernelGGL((k_fusedPass<false, true>), grid, dim3(256), 0, s, a, (uint32_t*)nullptr, list, list_count);
+        else hipLaunchKernelGGL((k_fusedPass<false, false>), grid, dim3(256), 0, s, a, (uint32_t*)nullptr, list, list_count);
+    }
 }
 bool fused_fast_available() { return PT_EXACT_FAST_DIV != 0; }
 void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count) {

@@ -145,10 +145,10 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     return a;
 }
 
-// One primitive set.  KIND / ANY as in pt_device.hpp.  n == 1: a single cell, every lane walks
-// the same list -> wave-uniform loop, scalar loads.  n > 1: per-lane 3-axis DDA.
+// One primitive set.  KIND / ANY as in pt_device.hpp.
+// trace_cell1: n == 1, a single cell, every lane walks the same list -> wave-uniform loop, scalar loads.
 template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false>
-PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer) {
+PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
     Hit ch;
@@ -158,53 +158,63 @@ PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     ch.gamma = 0.0f;
     SphereRay sr;
     if (KIND == SPHERES) sr = sphere_ray<FAST>(ray.d);
-
-    if (S.n == 1u) {
-        // axis_setup with n == 1: slab = 0, the cell exit is the far face as the reference computes
-        // it, lo + (0 + (d>=0)) * ((hi-lo)/1)   (A10 code.cl:699-707)
-        float tn[3];
-        if (S.exit_is_far_face) {  // host-verified: the cell's exit planes ARE the box's far planes (see mirt_abi.cpp)
-            tn[0] = bh.tfx; tn[1] = bh.tfy; tn[2] = bh.tfz;
-        } else {
-            const float lo[3] = {S.bound[0], S.bound[1], S.bound[2]}, hi[3] = {S.bound[4], S.bound[5], S.bound[6]};
-            const float oo[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
+    // axis_setup with n == 1: slab = 0, the cell exit is the far face as the reference computes
+    // it, lo + (0 + (d>=0)) * ((hi-lo)/1)   (A10 code.cl:699-707)
+    float tn[3];
+    if (S.exit_is_far_face) {  // host-verified: the cell's exit planes ARE the box's far planes (see mirt_abi.cpp)
+        tn[0] = bh.tfx; tn[1] = bh.tfy; tn[2] = bh.tfz;
+    } else {
+        const float lo[3] = {S.bound[0], S.bound[1], S.bound[2]}, hi[3] = {S.bound[4], S.bound[5], S.bound[6]};
+        const float oo[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float delta = (hi[k] - lo[k]) / 1.0f;
-                float xnext = lo[k] + (float)((dd[k] >= 0) ? 1 : 0) * delta;
-                tn[k] = (xnext - oo[k]) / dd[k];
-            }
+        for (int k = 0; k < 3; ++k) {
+            float delta = (hi[k] - lo[k]) / 1.0f;
+            float xnext = lo[k] + (float)((dd[k] >= 0) ? 1 : 0) * delta;
+            tn[k] = (xnext - oo[k]) / dd[k];
         }
-        const float cmin = bh.tmin;
-        const float cmax = cl_min(cl_min(tn[0], tn[1]), tn[2]);
-        const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
-        const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
-        bool done = false;
+    }
+    const float cmin = bh.tmin;
+    const float cmax = cl_min(cl_min(tn[0], tn[1]), tn[2]);
+    const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
+    bool done = false;
+    const float4* __restrict__ p = prims + (size_t)begin * (KIND == SPHERES ? 1u : 3u);   // one running pointer: immediate-offset scalar loads
 #if PT_UNROLL_UNIFORM > 1
 #pragma unroll PT_UNROLL_UNIFORM
 #endif
-        const float4* __restrict__ p = prims + (size_t)begin * (KIND == SPHERES ? 1u : 3u);   // one running pointer: immediate-offset scalar loads
-        for (uint32_t i = begin; i < end; ++i, p += (KIND == SPHERES ? 1 : 3)) {
-            float ti, b = 0.0f, gm = 0.0f;
-            bool hit;
-            if (KIND == SPHERES) {
-                hit = sph_test(ray.o, ray.d, sr, cmin, cmax, p[0], ti);
-            } else {
-                hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, gm);
-            }
-            const bool better = (int)!done & (int)hit & (int)(ti < ch.t);
-            ch.t = better ? ti : ch.t;          // selects, not a branch: some lane of an incoherent wave almost always hits
-            ch.idx = better ? i : ch.idx;
-            ch.beta = better ? b : ch.beta;
-            ch.gamma = better ? gm : ch.gamma;
-            if (ANY) {
-                done = done || better;
-                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every lane of the wave is blocked
-            }
+    for (uint32_t i = begin; i < end; ++i, p += (KIND == SPHERES ? 1 : 3)) {
+        float ti, b = 0.0f, gm = 0.0f;
+        bool hit;
+        if (KIND == SPHERES) {
+            hit = sph_test(ray.o, ray.d, sr, cmin, cmax, p[0], ti);
+        } else {
+            hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, gm);
         }
-        return ch;
+        const bool better = (int)!done & (int)hit & (int)(ti < ch.t);
+        ch.t = better ? ti : ch.t;          // selects, not a branch: some lane of an incoherent wave almost always hits
+        ch.idx = better ? i : ch.idx;
+        ch.beta = better ? b : ch.beta;
+        ch.gamma = better ? gm : ch.gamma;
+        if (ANY) {
+            done = done || better;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every lane of the wave is blocked
+        }
     }
+    return ch;
+}
 
+// trace_dda: n > 1, per-lane 3-axis DDA.
+template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false>
+PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer) {
+    const float4* __restrict__ prims = (const float4*)S.prims;
+    const uint32_t* __restrict__ off = (const uint32_t*)S.off;
+    Hit ch;
+    ch.idx = UINT32_MAX;
+    ch.t = ray.maxt;
+    ch.beta = 0.0f;
+    ch.gamma = 0.0f;
+    SphereRay sr;
+    if (KIND == SPHERES) sr = sphere_ray<FAST>(ray.d);
     Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, defer);
     Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, defer);
     Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, defer);
@@ -214,34 +224,36 @@ PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     //            iterations, repeated until each live lane holds a primitive or has left the grid;
     //   phase B: every live lane tests ONE primitive.
     // A lane's tests, their order and their [cmin, cmax] windows are exactly those of the nested loops.
-    const uint32_t zs = S.n * S.n, ys = S.n;
-    float t = bh.tmin, cmin = 0.0f, cmax = 0.0f;
-    uint32_t i = 0, end = 0;
-    bool opened = false;
+    const uint32_t zs = S.n * S.n, ys = S.n;   // n <= 1024 (check_grid): 24-bit multiplies are exact
+    float t = bh.tmin;
+    float cmin = t;
+    float cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+    uint32_t cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
+    uint32_t i = off[cell], end = off[cell + 1];
     for (;;) {
         bool alive = true;
         while (i == end) {
-            if (opened) {
-                if (ch.idx != UINT32_MAX) { alive = false; break; }
-                t = cmax;
-                if (t == ax.tnext) {
-                    ax.tnext += ax.dt;
-                    ax.slab += ax.dslab;
-                    if (t >= bh.tmax || ax.slab == ax.limit) { alive = false; break; }
-                } else if (t == ay.tnext) {
-                    ay.tnext += ay.dt;
-                    ay.slab += ay.dslab;
-                    if (t >= bh.tmax || ay.slab == ay.limit) { alive = false; break; }
-                } else {
-                    az.tnext += az.dt;
-                    az.slab += az.dslab;
-                    if (t >= bh.tmax || az.slab == az.limit) { alive = false; break; }
-                }
+            // close the cell: a hit inside it ends the walk (code.cl:768-771); else step the axis whose plane was reached.
+            // Kept as the reference's if / else-if / else chain: the walk is VALU-bound at a quarter of the lanes, and the
+            // branches cost scalar instructions, which are not the bottleneck (selects instead: 72.2 -> 77.6 ms on cornell_teapot3)
+            if (ch.idx != UINT32_MAX) { alive = false; break; }
+            t = cmax;
+            if (t == ax.tnext) {
+                ax.tnext += ax.dt;
+                ax.slab += ax.dslab;
+                if (t >= bh.tmax || ax.slab == ax.limit) { alive = false; break; }
+            } else if (t == ay.tnext) {
+                ay.tnext += ay.dt;
+                ay.slab += ay.dslab;
+                if (t >= bh.tmax || ay.slab == ay.limit) { alive = false; break; }
+            } else {
+                az.tnext += az.dt;
+                az.slab += az.dslab;
+                if (t >= bh.tmax || az.slab == az.limit) { alive = false; break; }
             }
-            opened = true;
             cmin = t;
             cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
-            const uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
+            cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
             i = off[cell];
             end = off[cell + 1];
         }
@@ -263,6 +275,12 @@ PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
         if (ANY && better) break;
     }
     return ch;
+}
+
+template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false>
+PT_DEV Hit trace_set(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer) {
+    if (S.n == 1u) return trace_cell1<KIND, ANY, RULE, FAST>(ray, bh, S);
+    return trace_dda<KIND, ANY, RULE, FAST>(ray, bh, S, defer);
 }
 
 }  // namespace pt

@@ -39,7 +39,7 @@ PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r1d_park_lds: FETCH_SIZE x 2 + WRITE_SIZE,
 # KiB -> bytes; gfx950 halves FETCH_SIZE on wide coalesced reads, MI355X_MICROARCH.md).  Valid for the default workload only.
-TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 14.79e9, "write_bytes": 55.27e9, "source": "profiles/r1d_park_lds/pmc_summary.json"}
+TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 10.66e9, "write_bytes": 10.62e9, "source": "profiles/r1f_nogrids_kernel/pmc_summary.json"}
 
 
 def cpu_baseline(packed_json, log):
@@ -181,12 +181,12 @@ def main():
                                + (f"; {world} row tiles + RCCL all_gather of RGBA8" if world > 1 else ""),
                    "width": sc.width, "height": sc.height, "rays_per_pixel": sc.rpp, "bounces": args.bounces,
                    "parallelism": f"rows/{world}"},
-        "roofline": {"kernel": "pt::k_fusedPass", "bound": "valu", "achieved": round(valu_tf, 2), "peak": PEAK_VALU_TFLOPS,
+        "roofline": {"kernel": "pt::k_fusedPass<true,false>", "bound": "valu", "achieved": round(valu_tf, 2), "peak": PEAK_VALU_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(valu_tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic,
                      "flops_per_sample": flops, "launch_ms": round(fused_ms, 3), "resolve_ms": round(resolve_ms, 3)},
-        "roofline_hbm": {"kernel": "pt::k_fusedPass", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
+        "roofline_hbm": {"kernel": "pt::k_fusedPass<true,false>", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
-                         "traffic_note": "algorithmic 21.2 GB/launch; the excess is register-spill scratch (56 B/lane) written back through L2",
+                         "traffic_note": "algorithmic 21.2 GB/launch; measured 21.3 GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes): no re-reads, no scratch",
                          "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

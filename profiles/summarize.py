@@ -18,7 +18,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mix", "pmc_sq3", "
     for k, v in agg.items():
         out.setdefault(k, {}).update({c: {"mean_per_dispatch": sum(x) / len(x), "dispatches": len(x)} for c, x in v.items()})
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
-f = out.get("pt::k_fusedPass", {})
+f = next((v for k, v in out.items() if "k_fusedPass<true" in k), out.get("pt::k_fusedPass", {}))
 g = lambda c: f.get(c, {}).get("mean_per_dispatch", float("nan"))
 waves = g("SQ_WAVES")
 print(open(os.path.join(dst, "kernel_stats.csv")).read().split("\n")[1])
