@@ -6,9 +6,11 @@
          bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[3], the one the metric is quoted on): scenes/cornell.xml packed by the
-reference host for 1920x1080, rays_per_pixel = 256 (16x16 lens grid), one progressive pass, 5 bounces,
-seeds s[id] = 1 + (mix32(id ^ 0x9E3779B9) mod 2147483646) generated on the device.  One "step" is one
-such frame: initTrace .. 5 bounces .. copyToPixel, through mirt_render_pass (one fused launch + resolve).
+reference host for 1920x1080, rays_per_pixel = 256 (16x16 lens grid), one progressive pass, depth 8 (eight
+bounces after the primary hit; the reference hard-codes five, A10 code.js:1829 -- `--bounces 5` measures that,
+and the default run reports it beside the headline in "depth5"), seeds s[id] = 1 + (mix32(id ^ 0x9E3779B9)
+mod 2147483646) generated on the device.  One "step" is one such frame: initTrace .. 8 bounces .. copyToPixel,
+through mirt_render_pass (one fused launch + resolve).
 Inputs (scene buffers, seeds) are resident in HBM before the timed region.
 
 N > 1: one process per GPU; the frame is cut into N contiguous row tiles (ray ids stay global, so the
@@ -39,10 +41,10 @@ PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r1d_park_lds: FETCH_SIZE x 2 + WRITE_SIZE,
 # KiB -> bytes; gfx950 halves FETCH_SIZE on wide coalesced reads, MI355X_MICROARCH.md).  Valid for the default workload only.
-TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 10.66e9, "write_bytes": 10.62e9, "source": "profiles/r1f_nogrids_kernel/pmc_summary.json"}
+TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 10.62e9, "write_bytes": 10.62e9, "source": "profiles/r1g_depth8/pmc_summary.json"}
 
 
-def cpu_baseline(packed_json, log):
+def cpu_baseline(packed_json, log, bounces):
     """The CPU oracle (our plain-C restatement, OpenMP over all host cores) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import a10_pass as A
@@ -57,11 +59,11 @@ def cpu_baseline(packed_json, log):
     cores = k.lib.oracle_num_threads()
     st = A.PassState(sc, A.make_seeds(sc.total_rays))
     t0 = time.perf_counter()
-    A.run_pass(k, sc, st)
+    A.run_pass(k, sc, st, bounces=bounces)
     dt = time.perf_counter() - t0
     log(f"cpu_baseline: {sc.total_rays} samples in {dt:.2f} s on {cores} threads")
     return {"value": round(sc.total_rays / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"cornell.xml {w}x{h} rpp{rpp} 1 pass 5 bounces ({sc.total_rays} samples, {dt:.1f} s wall)"}
+            "sample": f"cornell.xml {w}x{h} rpp{rpp} 1 pass {bounces} bounces ({sc.total_rays} samples, {dt:.1f} s wall)"}
 
 
 def main():
@@ -72,7 +74,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--rpp", type=int, default=256)
-    ap.add_argument("--bounces", type=int, default=5)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--no-depth5", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -169,7 +172,7 @@ def main():
     valu_tf = flops * local_samples / (fused_ms * 1e-3) / 1e12
     hbm_gbs = BYTES_PER_SAMPLE_FUSED * local_samples / (fused_ms * 1e-3) / 1e9
 
-    default_wl = (world == 1 and (sc.width, sc.height, sc.rpp, args.bounces) == (1920, 1080, 256, 5))
+    default_wl = (world == 1 and (sc.width, sc.height, sc.rpp, args.bounces) == (1920, 1080, 256, 8))
     traffic = (TRAFFIC_DEFAULT_WORKLOAD["fetch_bytes"] + TRAFFIC_DEFAULT_WORKLOAD["write_bytes"]) if default_wl else None
     out = {
         "metric": "Msamples/sec (pixels x spp) at 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
@@ -186,11 +189,22 @@ def main():
                      "flops_per_sample": flops, "launch_ms": round(fused_ms, 3), "resolve_ms": round(resolve_ms, 3)},
         "roofline_hbm": {"kernel": "pt::k_fusedPass<true,false>", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
-                         "traffic_note": "algorithmic 21.2 GB/launch; measured 21.3 GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes): no re-reads, no scratch",
+                         "traffic_note": "algorithmic 21.2 GB/launch; measured 21.2 GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes): no re-reads, no scratch",
                          "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(packed, log)
+        out["cpu_baseline"] = cpu_baseline(packed, log, args.bounces)
+    if rank == 0 and world == 1 and args.bounces == 8 and not args.no_depth5:
+        # the reference's own depth (five bounces), same frame, two untimed-warmup-free steps: reported beside the headline
+        t5 = []
+        for _ in range(2):
+            ctx.zero(fr.acu)
+            ctx.seed_fill(fr.seeds, fr.first_ray, fr.nrays, 0)
+            fr.passes = 1
+            fr.execute_render(bounces=5)
+            t5.append(ctx.pass_timing()[0])
+        out["depth5"] = {"launch_ms": round(float(np.mean(t5)), 3), "Msamples_per_s_kernel": round(fr.nrays / np.mean(t5) / 1e3, 1),
+                         "flops_per_sample": FLOPS_PER_SAMPLE[5], "frac": round(FLOPS_PER_SAMPLE[5] * fr.nrays / (np.mean(t5) * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4)}
     fr.release()
     ctx.destroy()
     if use_dist:

@@ -3,11 +3,11 @@
 # MIRT_OUT=... csrc/build.sh -D...), same process layout, same box; prints launch_ms per variant.
 set -uo pipefail
 for lib in ab/libmirt_*.so; do
-  r=$(MIRT_LIB_PATH="$PWD/$lib" timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu 2>/dev/null)
+  r=$(MIRT_LIB_PATH="$PWD/$lib" timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu --no-depth5 2>/dev/null)
   echo "$(basename $lib) $(echo "$r" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["roofline"]["launch_ms"], d["value"])' 2>/dev/null || echo FAILED)"
 done
 if [ "${AB_EXACT_ONLY:-0}" = 1 ]; then for lib in ab/libmirt_*.so; do
-  r=$(MIRT_EXACT_ONLY=1 MIRT_LIB_PATH="$PWD/$lib" timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu 2>/dev/null)
+  r=$(MIRT_EXACT_ONLY=1 MIRT_LIB_PATH="$PWD/$lib" timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu --no-depth5 2>/dev/null)
   echo "exact_only $(basename $lib) $(echo "$r" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["roofline"]["launch_ms"], d["value"])' 2>/dev/null || echo FAILED)"
 done; fi
 if [ -n "${AB_SCENES:-}" ]; then for lib in ab/libmirt_*.so; do

@@ -8,7 +8,7 @@ TAG="${1:-r1}"
 OUT="gpurun_out/prof_${TAG}"
 mkdir -p "${OUT}"
 export TMPDIR=/tmp
-BENCH=(python3 bench.py --steps 2 --warmup 1 --no-cpu)
+BENCH=(python3 bench.py --steps 2 --warmup 1 --no-cpu --no-depth5)
 rocprofv3 --kernel-trace --stats --output-format csv -d "${OUT}/trace" -- "${BENCH[@]}" > "${OUT}/trace.log" 2>&1 || exit 11
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "${OUT}/pmc_fetch" -- "${BENCH[@]}" > "${OUT}/pmc_fetch.log" 2>&1 || exit 12
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "${OUT}/pmc_write" -- "${BENCH[@]}" > "${OUT}/pmc_write.log" 2>&1 || exit 13
