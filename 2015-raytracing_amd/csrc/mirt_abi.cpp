@@ -77,7 +77,7 @@ enum ArgType { A_BUF, A_U32, A_F32, A_F16, A_AABB };
 enum KernelId {
     K_sizeofRay, K_sizeofPoi, K_initAcu, K_initTrace, K_sphereTrace, K_triangleTrace, K_meshTrace, K_lightRender,
     K_initShadowTrace, K_sphereShadowTrace, K_triangleShadowTrace, K_sceneRender, K_bouncePaths, K_copyToPixel,
-    K_a01_raytrace, K_a04_sizeofRay, K_a04_initTrace, K_a04_meshTrace, K_a07_sizeofRay, K_a07_initTrace, K_a07_meshTrace, K_COUNT
+    K_a01_raytrace, K_a04_sizeofRay, K_a04_initTrace, K_a04_meshTrace, K_a07_sizeofRay, K_a07_initTrace, K_a07_meshTrace, K_a07_molTrace, K_COUNT
 };
 
 struct KernelSpec { const char* name; KernelId id; std::vector<ArgType> args; };
@@ -108,6 +108,8 @@ static const std::vector<KernelSpec>& kernel_table() {
         {"A07:sizeofRay", K_a07_sizeofRay, {A_BUF}},
         {"A07:initTrace", K_a07_initTrace, {A_BUF, A_F16, A_BUF, A_AABB}},
         {"A07:meshTrace", K_a07_meshTrace, {A_BUF, A_F16, A_BUF, A_U32, A_BUF, A_BUF, A_BUF, A_BUF, A_AABB, A_U32, A_BUF}},
+        // molTrace(pixels, fcam, rays, s_size, s_atoms, s_mindex, m_color, bound, n_slabs, slab_size)   A07 code.cl:337-344
+        {"A07:molTrace", K_a07_molTrace, {A_BUF, A_F16, A_BUF, A_U32, A_BUF, A_BUF, A_BUF, A_AABB, A_U32, A_BUF}},
     };
     return t;
 }
@@ -652,7 +654,8 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
         case K_a04_initTrace:
         case K_a07_initTrace:
         case K_a04_meshTrace:
-        case K_a07_meshTrace: {
+        case K_a07_meshTrace:
+        case K_a07_molTrace: {
             if (dim != 2) return fail(ctx, MIRT_E_ARG, "%s is a 2-D NDRange", S.name);
             const uint32_t g1 = (uint32_t)global[1];
             const uint32_t cols = f2u_host(V(1)[14]), rows = f2u_host(V(1)[15]);
@@ -672,6 +675,10 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
                 if ((rc = ensure_prepared(ctx, BUF(4), T))) return rc;
                 pt::launch_a04_meshTrace(st, BUF(0)->ptr, V(1), BUF(2)->ptr, T, BUF(4)->prep, BUF(5)->ptr, BUF(6)->ptr, BUF(7)->ptr,
                                          (uint32_t)(BUF(7)->bytes / 16), g0, g1);
+            } else if (S.id == K_a07_molTrace) {
+                // s_mindex / m_color (args 5, 6) are bound by the reference host but never read by the kernel (code.cl:459-460)
+                if ((rc = check_grid(ctx, "molTrace grid", BUF(9), U(8), BUF(4), 16, nullptr, nullptr))) return rc;
+                pt::launch_a07_molTrace(st, BUF(0)->ptr, V(1), BUF(2)->ptr, BUF(4)->ptr, V(7), U(8), BUF(9)->ptr, g0, g1);
             } else {
                 if ((rc = check_grid(ctx, "meshTrace grid", BUF(10), U(9), BUF(4), 48, BUF(5), nullptr))) return rc;
                 if ((rc = ensure_prepared(ctx, BUF(4), BUF(10)->off_last))) return rc;

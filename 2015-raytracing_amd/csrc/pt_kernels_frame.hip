@@ -179,6 +179,70 @@ __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16
     pixels[pix] = make_uchar4(f2u8((float)((hx % 2) + 1) * k), f2u8((float)((hy % 2) + 1) * k), f2u8((float)((hz % 2) + 1) * k), 255);
 }
 
+// ---- Assign07 molTrace (code.cl:337-473): the same grid walk over atoms {c, r*r}; colour = parity of the hit cell x fake shade.
+// The hit record keeps the CELL of the champion (champ_slab, code.cl:402, 425-429): the walk ends once any cell produced one.
+__global__ void __launch_bounds__(256) k_a07_molTrace(uchar4* pixels, F16 cam16, RayAoS* rays, const float4* atoms, Box8 bound8, uint32_t n_slabs,
+                                                       const uint32_t* slab_size, uint32_t gx, uint32_t gy) {
+    const Cam cam = mk_cam(cam16);
+    uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t row = blockIdx.y * blockDim.y + threadIdx.y;
+    if (col >= gx || row >= gy || col >= cam.cols || row >= cam.rows) return;
+    const size_t pix = (size_t)cam.cols * row + col;
+    Ray ray = load_ray48(&rays[pix]);
+    if (ray.mint == ray.maxt) return;
+    const Box bound = mk_box(bound8);
+    BoxHit bh = inter_aabb(ray, bound);
+    if (!bh.v) return;
+    Axis ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, bound.lo.x, bound.hi.x, n_slabs);
+    Axis ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, bound.lo.y, bound.hi.y, n_slabs);
+    Axis az = axis_setup(ray.o.z, ray.d.z, bh.tmin, bound.lo.z, bound.hi.z, n_slabs);
+    const SphereRay sr = sphere_ray<false>(ray.d);
+    float champ_t = ray.maxt;
+    uint32_t champ_i = UINT32_MAX;
+    int hx = 0, hy = 0, hz = 0;
+    const uint32_t zs = n_slabs * n_slabs, ys = n_slabs;
+    // phase A / phase B as in trace_dda (pt_trace.hpp): close and open cells until every live lane holds an atom, then one test each
+    float t = bh.tmin, cmin = t, cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+    uint32_t cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
+    uint32_t i = slab_size[cell], end = slab_size[cell + 1];
+    for (;;) {
+        bool alive = true;
+        while (i == end) {
+            if (champ_i != UINT32_MAX) { alive = false; break; }
+            t = cmax;
+            if (t == ax.tnext) {
+                ax.tnext += ax.dt;
+                ax.slab += ax.dslab;
+                if (t >= bh.tmax || ax.slab == ax.limit) { alive = false; break; }
+            } else if (t == ay.tnext) {
+                ay.tnext += ay.dt;
+                ay.slab += ay.dslab;
+                if (t >= bh.tmax || ay.slab == ay.limit) { alive = false; break; }
+            } else {
+                az.tnext += az.dt;
+                az.slab += az.dslab;
+                if (t >= bh.tmax || az.slab == az.limit) { alive = false; break; }
+            }
+            cmin = t;
+            cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+            cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
+            i = slab_size[cell];
+            end = slab_size[cell + 1];
+        }
+        if (!alive) break;
+        float ti;
+        const bool hit = sph_test(ray.o, ray.d, sr, cmin, cmax, atoms[i], ti);
+        if (hit && ti < champ_t) { champ_t = ti; champ_i = i; hx = ax.slab; hy = ay.slab; hz = az.slab; }
+        ++i;
+    }
+    if (champ_i == UINT32_MAX) return;
+    rays[pix].maxt = champ_t;
+    const f3 ip = add3(ray.o, scl3(champ_t, ray.d));
+    const float shade = cl_clamp(dot3(cam.W, norm3(sub3(ip, ld3(atoms[champ_i])))), 0.0f, 1.0f);   // code.cl:455-457
+    const float k = shade * 127.0f;                                                                // code.cl:463-469
+    pixels[pix] = make_uchar4(f2u8((float)((hx % 2) + 1) * k), f2u8((float)((hy % 2) + 1) * k), f2u8((float)((hz % 2) + 1) * k), 255);
+}
+
 static F16 mk16f(const float* f) { F16 r; for (int i = 0; i < 16; ++i) r.v[i] = f[i]; return r; }
 static Box8 mk8f(const float* f) { Box8 r; for (int i = 0; i < 8; ++i) r.v[i] = f ? f[i] : 0.0f; return r; }
 static dim3 grid2(uint32_t gx, uint32_t gy) { return dim3((gx + 31) / 32, (gy + 7) / 8); }
@@ -203,6 +267,13 @@ void launch_a07_meshTrace(hipStream_t s, void* pixels, const float* cam, void* r
     if (!gx || !gy) return;
     hipLaunchKernelGGL(k_a07_meshTrace, grid2(gx, gy), dim3(32, 8), 0, s, (uchar4*)pixels, mk16f(cam), (RayAoS*)rays, (const float4*)prep,
                        (const float4*)normals, mk8f(bound), n_slabs, (const uint32_t*)slab_size, gx, gy);
+}
+
+void launch_a07_molTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* atoms, const float* bound, uint32_t n_slabs,
+                         const void* slab_size, uint32_t gx, uint32_t gy) {
+    if (!gx || !gy) return;
+    hipLaunchKernelGGL(k_a07_molTrace, grid2(gx, gy), dim3(32, 8), 0, s, (uchar4*)pixels, mk16f(cam), (RayAoS*)rays, (const float4*)atoms, mk8f(bound),
+                       n_slabs, (const uint32_t*)slab_size, gx, gy);
 }
 
 }  // namespace pt

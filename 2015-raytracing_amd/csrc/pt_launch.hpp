@@ -91,5 +91,7 @@ void launch_a04_meshTrace(hipStream_t s, void* pixels, const float* cam, void* r
                           const void* mindex, const void* mcolor, uint32_t ncolors, uint32_t gx, uint32_t gy);
 void launch_a07_meshTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* prep, const void* normals, const float* bound,
                           uint32_t n_slabs, const void* slab_size, uint32_t gx, uint32_t gy);
+void launch_a07_molTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* atoms, const float* bound, uint32_t n_slabs,
+                         const void* slab_size, uint32_t gx, uint32_t gy);
 
 }  // namespace pt

@@ -3,7 +3,7 @@
 //   node cli.js pack   <scene.xml> <width> <height> <raysPerPixel>                 -> packed kernel inputs as JSON (stdout)
 //   node cli.js render <scene.xml> <width> <height> <raysPerPixel> <passes> <out.rgba> [--granular] [--device-grid] [--bounces N] [--seeds file.i32]
 //                                                                                   -> RGBA8 frame (+ <out>.radiance.f32) via the N-API addon
-//   node cli.js pack-frame <1|4|7> <mesh.json|-> <width> <height> [nSlabs]          -> packed inputs of an Assign01/04/07 frame job (stdout)
+//   node cli.js pack-frame <1|4|7> <mesh.json|mol.pdb|-> <width> <height> [nSlabs]  -> packed inputs of an Assign01/04/07 frame job (stdout)
 //   node cli.js frame      <1|4|7> <mesh.json|-> <width> <height> <nSlabs|0> <out.rgba>  -> RGBA8 frame of that job
 //   node cli.js devices                                                             -> what webcl.getPlatforms()/getDevices() report
 "use strict";
@@ -39,7 +39,8 @@ if (cmd === "pack") {
 } else if (cmd === "pack-frame" || cmd === "frame") {
   if (rest.length < 4) usage();
   const frame = require("./frame.js");
-  const assign = +rest[0], model = rest[1] === "-" ? null : JSON.parse(fs.readFileSync(rest[1], "utf8").replace(/^\ufeff/, ""));
+  const assign = +rest[0], text = rest[1] === "-" ? null : fs.readFileSync(rest[1], "utf8").replace(/^\ufeff/, "");
+  const model = text === null ? null : /\.pdb$/i.test(rest[1]) ? { pdb: text } : JSON.parse(text);   // .pdb: Assign07's molecule mode
   const p = frame.packFrame(assign, model, +rest[2], +rest[3], +rest[4] || 2);
   if (cmd === "pack-frame") process.stdout.write(JSON.stringify(scene.packedToJSON(p)));
   else { const px = frame.renderFrame(p); fs.writeFileSync(rest[5], Buffer.from(px.buffer, px.byteOffset, px.byteLength)); }

@@ -2,17 +2,19 @@
 //   Assign01 compute()      one hard-coded sphere, kernel `raytrace`                (A01 code.js:166-269)
 //   Assign04 computeTri()   brute-force mesh, kernels `initTrace`, `meshTrace`      (A04 code.js:553-577, 396-497)
 //   Assign07 computeTri()   3-D uniform grid,  kernels `initTrace`, `meshTrace`     (A07 code.js:603-628, 398-557, 980-1122)
+//   Assign07 compute()      molecule (.pdb) as spheres in the same grid, kernels `initTrace`, `molTrace`   (A07 code.js:569-600, 434-470, 889-978)
 // packFrame() produces the exact typed arrays those hosts upload; FrameRenderer enqueues the kernels in the same
 // order through the WebCL-shaped API (./webcl.js), selecting the kernel set by program dialect.
 "use strict";
 const { webcl } = require("./webcl.js");
 const scene = require("./scene.js");
+const { parsePDB } = require("./pdb.js");
 
 // what createProgram() gets in place of code.cl: enough text for the runtime to recognise the kernel set
 const MANIFEST = {
   1: "__kernel void raytrace(__global uchar4* pixels, float16 fcam);",
   4: "__kernel void sizeofRay(__global uint* s);\n__kernel void initTrace();\n__kernel void meshTrace(uint t_size);",
-  7: "__kernel void sizeofRay(__global uint* s);\n__kernel void initTrace();\n__kernel void meshTrace(uint t_size, uint z_stride);",
+  7: "__kernel void sizeofRay(__global uint* s);\n__kernel void initTrace();\n__kernel void meshTrace(uint t_size, uint z_stride);\n__kernel void molTrace(uint s_size);",
 };
 
 function packFrame(assign, model, width, height, nSlabs) {
@@ -22,6 +24,7 @@ function packFrame(assign, model, width, height, nSlabs) {
     const f = cam.toFloat32Array(); f[14] = height; f[15] = width;
     return { assign: 1, width: width, height: height, cam: f };
   }
+  if (assign === 7 && model && typeof model.pdb === "string") return packMol(parsePDB(model.pdb), cam, width, height, nSlabs);   // { pdb: <file text> }
   const md = scene.parseMeshJSON(model);
   cam.defaultInit(); cam.set(md.bounds, width, height);
   const p = { assign: assign, width: width, height: height, cam: cam.toFloat32Array(), bounds: scene.bounds2AABB(md.bounds),
@@ -55,6 +58,27 @@ function packFrame(assign, model, width, height, nSlabs) {
   return p;
 }
 
+// splitMolData (A07 code.js:889-978): the sphere binning of A10's splitSphereData over (type, x, y, z) records; slots carry
+// (c, r*r) and the atom's type index.  The loop runs to `size` (largest serial), past the packed atoms when serials have gaps:
+// those reads are undefined -> NaN boxes -> no cell, exactly as in the page.
+function packMol(mol, cam, width, height, nSlabs) {
+  cam.defaultInit(); cam.set(mol.bounds, width, height);
+  const A = mol.atomData, rad = (i) => mol.radiusData[A[4 * i]];
+  const g = scene.buildGrid(mol.size, nSlabs, mol.bounds, (i) => {
+    const r = rad(i), x = A[4 * i + 1], y = A[4 * i + 2], z = A[4 * i + 3];
+    return [[x - r, y - r, z - r], [x + r, y + r, z + r]];
+  });
+  const n = g.order.length, atoms = new Float32Array(4 * n), mindex = new Uint32Array(n);
+  for (let k = 0; k < n; k++) {
+    const i = g.order[k], r = rad(i);
+    atoms[4 * k] = A[4 * i + 1]; atoms[4 * k + 1] = A[4 * i + 2]; atoms[4 * k + 2] = A[4 * i + 3]; atoms[4 * k + 3] = r * r;
+    mindex[k] = A[4 * i];
+  }
+  return { assign: 7, width: width, height: height, cam: cam.toFloat32Array(), bounds: scene.bounds2AABB(mol.bounds), n_slabs: nSlabs, s_size: mol.size,
+           atoms: atoms, mindex: mindex, slab_size: g.offsets, mcolor: new Float32Array(mol.colorData),
+           pdb: { size: mol.size, atomData: mol.atomData, colorData: mol.colorData, radiusData: mol.radiusData, min: mol.bounds.min, max: mol.bounds.max } };
+}
+
 const ceilTo = (n, m) => Math.ceil(n / m) * m;
 
 function renderFrame(p, opt) {
@@ -77,12 +101,15 @@ function renderFrame(p, opt) {
     const sk = prog.createKernel("sizeofRay"), sb = ctx.createBuffer(webcl.MEM_WRITE_ONLY, 4), so = new Uint32Array(1);   // getRaySize
     sk.setArg(0, sb); q.enqueueNDRangeKernel(sk, 1, null, [1], [1]); q.enqueueReadBuffer(sb, false, 0, 4, so, []); q.finish(); sb.release(); sk.release();
     const rays = buf(webcl.MEM_READ_WRITE, w * h * so[0]);
-    const it = prog.createKernel("initTrace"), mt = prog.createKernel("meshTrace"); res.push(it, mt);
+    const it = prog.createKernel("initTrace"), mt = prog.createKernel(p.atoms ? "molTrace" : "meshTrace"); res.push(it, mt);
     it.setArg(0, pixels); it.setArg(1, p.cam); it.setArg(2, rays);
     if (p.assign === 7) it.setArg(3, p.bounds);
     const RO = webcl.MEM_READ_ONLY;
-    [pixels, p.cam, rays, new Uint32Array([p.t_size]), buf(RO, p.pos), buf(RO, p.normal), buf(RO, p.mindex), buf(RO, p.mcolor)].forEach((v, i) => mt.setArg(i, v));
-    if (p.assign === 7) { mt.setArg(8, p.bounds); mt.setArg(9, new Uint32Array([p.n_slabs])); mt.setArg(10, buf(RO, p.slab_size)); }
+    if (p.atoms) {   // prepareMolTrace (A07 code.js:434-470): ten arguments
+      [pixels, p.cam, rays, new Uint32Array([p.s_size]), buf(RO, p.atoms), buf(RO, p.mindex), buf(RO, p.mcolor), p.bounds, new Uint32Array([p.n_slabs]),
+       buf(RO, p.slab_size)].forEach((v, i) => mt.setArg(i, v));
+    } else [pixels, p.cam, rays, new Uint32Array([p.t_size]), buf(RO, p.pos), buf(RO, p.normal), buf(RO, p.mindex), buf(RO, p.mcolor)].forEach((v, i) => mt.setArg(i, v));
+    if (p.assign === 7 && !p.atoms) { mt.setArg(8, p.bounds); mt.setArg(9, new Uint32Array([p.n_slabs])); mt.setArg(10, buf(RO, p.slab_size)); }
     q.enqueueNDRangeKernel(it, 2, null, gws, lws);
     q.enqueueNDRangeKernel(mt, 2, null, gws, lws);
   }
@@ -94,4 +121,4 @@ function renderFrame(p, opt) {
   return out;
 }
 
-module.exports = { packFrame, renderFrame, MANIFEST };
+module.exports = { packFrame, packMol, renderFrame, MANIFEST };

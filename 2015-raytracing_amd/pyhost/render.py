@@ -212,7 +212,13 @@ class FramePacked:
     def __init__(self, d):
         self.assign, self.width, self.height = int(d["assign"]), int(d["width"]), int(d["height"])
         self.cam = np.asarray(d["cam"], np.float32)
-        if self.assign != 1:
+        self.mol = "atoms" in d       # A07 molecule mode: parsePDB + splitMolData + molTrace (A07 code.js:569-600)
+        if self.mol:
+            self.bounds = np.asarray(d["bounds"], np.float32)
+            self.s_size = int(d["s_size"])
+            self.atoms = np.asarray(d["atoms"], np.float32)
+            self.mindex, self.mcolor = np.asarray(d["mindex"], np.uint32), np.asarray(d["mcolor"], np.float32)
+        elif self.assign != 1:
             self.bounds = np.asarray(d["bounds"], np.float32)
             self.t_size = int(d["t_size"])
             self.pos, self.normal = np.asarray(d["pos"], np.float32), np.asarray(d["normal"], np.float32)
@@ -247,6 +253,14 @@ def render_frame(ctx, p):
         it = ctx.kernel(pre + "initTrace").set_args(pixels, p.cam, rays)
         if p.assign == 7:
             it.set_arg(3, p.bounds)
+        if p.mol:   # prepareMolTrace / executeMolTrace (A07 code.js:434-470, 549-552): ten arguments, s_mindex / m_color bound but unread
+            mt = ctx.kernel(pre + "molTrace").set_args(pixels, p.cam, rays, _u32(p.s_size), up(p.atoms), up(p.mindex), up(p.mcolor), p.bounds,
+                                                       _u32(p.n_slabs), up(p.slab_size))
+            it.enqueue(gws, l)
+            mt.enqueue(gws, l)
+            ctx.finish()
+            it.release(); mt.release()
+            return pixels.read(np.uint8).reshape(-1, 4), rays.read(np.uint8)
         mt = ctx.kernel(pre + "meshTrace").set_args(pixels, p.cam, rays, _u32(p.t_size), up(p.pos), up(p.normal), up(p.mindex), up(p.mcolor))
         if p.assign == 7:
             mt.set_arg(8, p.bounds).set_arg(9, _u32(p.n_slabs)).set_arg(10, up(p.slab_size))

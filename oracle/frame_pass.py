@@ -37,7 +37,13 @@ class Frame:
         self.d = d
         self.assign, self.width, self.height = int(d["assign"]), int(d["width"]), int(d["height"])
         self.cam = np.asarray(d["cam"], np.float32)
-        if self.assign != 1:
+        self.mol = "atoms" in d                                   # A07 molecule mode (parsePDB + splitMolData + molTrace)
+        if self.mol:
+            self.bounds = np.asarray(d["bounds"], np.float32)
+            self.s_size = int(d["s_size"])
+            self.atoms = np.asarray(d["atoms"], np.float32)
+            self.mindex, self.mcolor = np.asarray(d["mindex"], np.uint32), np.asarray(d["mcolor"], np.float32)
+        elif self.assign != 1:
             self.bounds = np.asarray(d["bounds"], np.float32)
             self.t_size = int(d["t_size"])
             self.pos, self.normal = np.asarray(d["pos"], np.float32), np.asarray(d["normal"], np.float32)
@@ -64,6 +70,12 @@ def run_frame(kind, fr):
         f(_p(pixels), cp, _p(rays), gx, gy)
         f = getattr(lib, pre + "meshTrace"); f.argtypes = [vp, fp, vp, u, vp, vp, vp, vp, sz, sz]; f.restype = None
         f(_p(pixels), cp, _p(rays), fr.t_size, _p(fr.pos), _p(fr.normal), _p(fr.mindex), _p(fr.mcolor), gx, gy)
+    elif fr.mol:
+        bp, _b = _f(fr.bounds)
+        f = getattr(lib, pre + "initTrace"); f.argtypes = [vp, fp, vp, fp, sz, sz]; f.restype = None
+        f(_p(pixels), cp, _p(rays), bp, gx, gy)
+        f = getattr(lib, pre + "molTrace"); f.argtypes = [vp, fp, vp, u, vp, vp, vp, fp, u, vp, sz, sz]; f.restype = None
+        f(_p(pixels), cp, _p(rays), fr.s_size, _p(fr.atoms), _p(fr.mindex), _p(fr.mcolor), bp, fr.n_slabs, _p(fr.slab_size), gx, gy)
     else:
         bp, _b = _f(fr.bounds)
         f = getattr(lib, pre + "initTrace"); f.argtypes = [vp, fp, vp, fp, sz, sz]; f.restype = None

@@ -30,6 +30,12 @@ CASES = [
     ("frame_a07_teapot_n2_160x120", 7, "teapot.json", 160, 120, 2, False),   # n_slabs 2 = the page's default
     ("frame_a07_teapot_n8_160x120", 7, "teapot.json", 160, 120, 8, False),
     ("frame_a07_parliament_n16_160x120", 7, "house_of_parliament.json", 160, 120, 16, False),   # config 3's mesh
+    ("frame_a07_mol_benzene_n2_96x64", 7, "benzene.pdb", 96, 64, 2, False),      # molecule mode, the page's default n_slabs
+    ("frame_a07_mol_c60_n4_160x120", 7, "c60.pdb", 160, 120, 4, False),
+    ("frame_a07_mol_dna_n8_160x120", 7, "dna.pdb", 160, 120, 8, False),
+    ("frame_a07_mol_3IZ4_n16_96x64", 7, "3IZ4.pdb", 96, 64, 16, False),          # the page's largest molecule: the sphere walk at scale
+    ("frame_a07_own_mol_helix_n3_96x64", 7, "helix.pdb", 96, 64, 3, True),       # every reader quirk (tests/scenes/make_molecules.py)
+    ("frame_a07_own_mol_lattice_n6_96x64", 7, "lattice.pdb", 96, 64, 6, True),
     ("frame_a04_own_icosphere_96x64", 4, "icosphere.json", 96, 64, 0, True),
     ("frame_a07_own_terrain_n5_96x64", 7, "terrain.json", 96, 64, 5, True),
     ("frame_a07_own_octahedra_n3_96x64", 7, "octahedra.json", 96, 64, 3, True),

@@ -40,6 +40,19 @@ let out;
 if (assign === "1") {
   out = vm.runInContext(`(function(){ var f32=${f32}; var cam = new Camera(); cam.defaultInit(); cam.width = 2.66; cam.height = 2.0; cam.cols = ${+W}; cam.rows = ${+H};
     return { assign: 1, width: ${+W}, height: ${+H}, cam: f32(cam.toFloat32Array()) }; })()`, sandbox);   // A01 code.js:180-185
+} else if (/\.pdb$/.test(meshName)) {
+  // A07 molecule mode: compute() (A07 code.js:569-600): parsePDB, cam.set(bounds), splitMolData; `pdb` keeps parsePDB's own output
+  vm.runInContext(`width=${+W}; height=${+H}; n_slabs=${+NSLABS > 0 ? +NSLABS : 2};`, sandbox);
+  out = vm.runInContext(`(function(){
+    var f32=${f32}, u32=${u32};
+    var molData = parsePDB(loadFromFile("mol/${meshName}"));
+    cam.defaultInit(); cam.set(molData.bounds, width, height);
+    var pd=[], id=[], sd=[]; splitMolData(molData, pd, id, sd);
+    return { assign: 7, mol: "${meshName}", width: width, height: height, cam: f32(cam.toFloat32Array()), n_slabs: n_slabs, s_size: molData.size,
+             bounds: f32([molData.bounds.min[0], molData.bounds.min[1], molData.bounds.min[2], 1, molData.bounds.max[0], molData.bounds.max[1], molData.bounds.max[2], 1]),
+             atoms: f32(pd), mindex: u32(id), slab_size: u32(sd), mcolor: f32(molData.colorData),
+             pdb: { size: molData.size, atomData: molData.atomData, colorData: molData.colorData, radiusData: molData.radiusData,
+                    min: molData.bounds.min, max: molData.bounds.max } }; })()`, sandbox);
 } else {
   vm.runInContext(`width=${+W}; height=${+H}; ${assign === "7" ? "n_slabs=" + (+NSLABS > 0 ? +NSLABS : 2) + ";" : ""}`, sandbox);
   out = vm.runInContext(`(function(){

@@ -833,3 +833,60 @@ void oracle_a07_meshTrace(void* pixels_, const float* cam16, void* rays_, unsign
             pixels[4 * pix + 3] = 255;
         }
 }
+
+/* A07 code.cl:337-473: the grid walk over atoms {c, r*r}; the champion keeps its CELL (champ_slab, :402, :425-429), whose
+ * parity colours the pixel; shade = clamp(dot(W, normalize(p - c))) (:455-469).  s_mindex / m_color are bound, never read. */
+void oracle_a07_molTrace(void* pixels_, const float* cam16, void* rays_, unsigned s_size, void* atoms_, unsigned* mindex, void* mcolor,
+                         const float* bound8, unsigned n_slabs, unsigned* slab_size, size_t gx, size_t gy) {
+    (void)s_size; (void)mindex; (void)mcolor;
+    uint8_t* pixels = (uint8_t*)pixels_;
+    pto_ray* rays = (pto_ray*)rays_;
+    const float* atoms = (const float*)atoms_;
+    cam_t cam = ld_cam(cam16);
+    box_t bound = ld_box(bound8);
+    const long rows = (long)(gy < cam.rows ? gy : cam.rows);
+    const size_t cols = gx < cam.cols ? gx : cam.cols;
+    const uint32_t n = n_slabs, zs = n * n, ys = n;
+    PAR_ROWS
+    for (long row = 0; row < rows; ++row)
+        for (size_t col = 0; col < cols; ++col) {
+            size_t pix = (size_t)cam.cols * (size_t)row + col;
+            ray_t ray = ld_ray(&rays[pix]);
+            if (ray.mint == ray.maxt) continue;
+            boxhit_t bh = inter_aabb(&ray, &bound);
+            if (!bh.v) continue;
+            axis_t ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, bound.pmin.x, bound.pmax.x, n);
+            axis_t ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, bound.pmin.y, bound.pmax.y, n);
+            axis_t az = axis_setup(ray.o.z, ray.d.z, bh.tmin, bound.pmin.z, bound.pmax.z, n);
+            float champ_t = ray.maxt, t = bh.tmin;
+            uint32_t champ_i = UINT_MAX;
+            int hx = 0, hy = 0, hz = 0;
+            for (;;) {
+                ray.mint = t;
+                ray.maxt = cln_min(cln_min(ax.tnext, ay.tnext), az.tnext);
+                uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
+                for (uint32_t i = slab_size[cell]; i < slab_size[cell + 1]; ++i) {
+                    float ti;
+                    if (inter_sphere(&ray, atoms + 4u * (size_t)i, &ti) && ti < champ_t) {
+                        champ_t = ti; champ_i = i; hx = ax.slab; hy = ay.slab; hz = az.slab;
+                    }
+                }
+                if (champ_i != UINT_MAX) break;
+                t = ray.maxt;
+                if (t == ax.tnext) { ax.tnext += ax.dt; if (t >= bh.tmax) break; ax.slab += ax.dslab; if (ax.slab == ax.limit) break; }
+                else if (t == ay.tnext) { ay.tnext += ay.dt; if (t >= bh.tmax) break; ay.slab += ay.dslab; if (ay.slab == ay.limit) break; }
+                else { az.tnext += az.dt; if (t >= bh.tmax) break; az.slab += az.dslab; if (az.slab == az.limit) break; }
+            }
+            if (champ_i == UINT_MAX) continue;
+            rays[pix].maxt = champ_t;
+            const float* a = atoms + 4u * (size_t)champ_i;
+            v3 ip = add(ray.o, scl(champ_t, ray.d));
+            v3 c = {a[0], a[1], a[2]};
+            float shade = cln_clamp(dot3(cam.W, norm3(sub(ip, c))), 0.0f, 1.0f);
+            float k = shade * 127.0f;
+            pixels[4 * pix + 0] = f2u8((float)((hx % 2) + 1) * k);
+            pixels[4 * pix + 1] = f2u8((float)((hy % 2) + 1) * k);
+            pixels[4 * pix + 2] = f2u8((float)((hz % 2) + 1) * k);
+            pixels[4 * pix + 3] = 255;
+        }
+}

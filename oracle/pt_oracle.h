@@ -58,6 +58,8 @@ void oracle_a04_meshTrace(void* pixels, const float* cam, void* rays, unsigned t
 void oracle_a07_initTrace(void* pixels, const float* cam, void* rays, const float* bound, size_t gx, size_t gy);
 void oracle_a07_meshTrace(void* pixels, const float* cam, void* rays, unsigned t_size, void* pos, void* nor, unsigned* mindex,
                           void* mcolor, const float* bound, unsigned n_slabs, unsigned* slab_size, size_t gx, size_t gy);
+void oracle_a07_molTrace(void* pixels, const float* cam, void* rays, unsigned s_size, void* atoms, unsigned* mindex, void* mcolor,
+                         const float* bound, unsigned n_slabs, unsigned* slab_size, size_t gx, size_t gy);
 
 /* built-in probes (tests compare them with the functions the compiled reference called) */
 float oracle_bi_sin(float x);

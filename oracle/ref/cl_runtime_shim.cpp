@@ -261,6 +261,7 @@ extern "C" {
 void __clang_ocl_kern_imp_sizeofRay(unsigned*);
 void __clang_ocl_kern_imp_initTrace(uchar4*, float16, Ray*, AABB);
 void __clang_ocl_kern_imp_meshTrace(uchar4*, float16, Ray*, unsigned, float3*, float3*, unsigned*, float4*, AABB, unsigned, unsigned*);
+void __clang_ocl_kern_imp_molTrace(uchar4*, float16, Ray*, unsigned, float4*, unsigned*, float4*, AABB, unsigned, unsigned*);
 unsigned ref_a07_sizeofRay(void) { unsigned s = 0; g_gid[0] = 0; __clang_ocl_kern_imp_sizeofRay(&s); return s; }
 void ref_a07_initTrace(void* pixels, const float* cam, void* rays, const float* bound, size_t gx, size_t gy) {
     float16 c = mk16(cam);
@@ -273,6 +274,12 @@ void ref_a07_meshTrace(void* pixels, const float* cam, void* rays, unsigned t_si
     AABB b = mkbox(bound);
     FOR_2D(gx, gy) __clang_ocl_kern_imp_meshTrace((uchar4*)pixels, c, (Ray*)rays, t_size, (float3*)pos, (float3*)nor, mindex, (float4*)mcolor,
                                                   b, n_slabs, slab_size);
+}
+void ref_a07_molTrace(void* pixels, const float* cam, void* rays, unsigned s_size, void* atoms, unsigned* mindex, void* mcolor,
+                      const float* bound, unsigned n_slabs, unsigned* slab_size, size_t gx, size_t gy) {
+    float16 c = mk16(cam);
+    AABB b = mkbox(bound);
+    FOR_2D(gx, gy) __clang_ocl_kern_imp_molTrace((uchar4*)pixels, c, (Ray*)rays, s_size, (float4*)atoms, mindex, (float4*)mcolor, b, n_slabs, slab_size);
 }
 }
 #endif

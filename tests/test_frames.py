@@ -18,6 +18,7 @@ CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, 
 node = shutil.which("node")
 REF = "/root/reference"
 REF_TRI = {4: f"{REF}/Assign04-Triangle_Mesh/tri", 7: f"{REF}/Assign07-3D_uniform_grid_acceleration/tri"}
+REF_MOL = f"{REF}/Assign07-3D_uniform_grid_acceleration/mol"
 
 
 def fixture(name):
@@ -46,6 +47,9 @@ def test_a01_fixture_is_the_expected_sphere():
 def mesh_path(d, name):
     if d["assign"] == 1:
         return "-"
+    if "mol" in d:   # Assign07's molecule mode
+        p = os.path.join(PAGE, "mol", d["mol"]) if "own" in name else os.path.join(REF_MOL, d["mol"])
+        return p if os.path.exists(p) else None
     p = os.path.join(PAGE, "tri", d["mesh"]) if "own" in name else os.path.join(REF_TRI[d["assign"]], d["mesh"])
     return p if os.path.exists(p) else None
 
@@ -61,11 +65,15 @@ def test_js_host_packs_frames_like_the_reference_host(name):
                         str(d.get("n_slabs", 0))], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
     got = json.loads(r.stdout)
+    same = lambda a, b: np.array_equal(np.asarray(a, np.float64), np.asarray(b, np.float64), equal_nan=True)   # JSON null = undefined radius
     for k, v in d.items():
-        if k == "mesh":
+        if k in ("mesh", "mol"):
             continue
         if isinstance(v, list):
-            assert np.array_equal(np.asarray(v, np.float64), np.asarray(got[k], np.float64)), k
+            assert same(v, got[k]), k
+        elif isinstance(v, dict):   # "pdb": the molecule reader's own output (size, atomData, colorData, radiusData, min, max)
+            for kk, vv in v.items():
+                assert same(vv, got[k][kk]) if isinstance(vv, list) else vv == got[k][kk], f"{k}.{kk}"
         else:
             assert v == got[k], k
 
@@ -132,7 +140,9 @@ def resized(d, w, h):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,size", [("frame_a04_parliament_96x64", (1024, 1024)),            # BASELINE config 2: 9144 triangles, brute force
                                        ("frame_a07_parliament_n16_160x120", (1920, 1080)),       # BASELINE config 3: same mesh, 16^3 grid
-                                       ("frame_a04_own_icosphere_96x64", (1024, 1024)), ("frame_a07_own_octahedra_n3_96x64", (1920, 1080))])
+                                       ("frame_a04_own_icosphere_96x64", (1024, 1024)), ("frame_a07_own_octahedra_n3_96x64", (1920, 1080)),
+                                       ("frame_a07_mol_3IZ4_n16_96x64", (1920, 1080)),           # molecule mode at scale: 8.9 k atoms, 16^3 grid
+                                       ("frame_a07_own_mol_lattice_n6_96x64", (1920, 1080))])
 def test_full_size_frames_against_oracle(ctx, pkg, name, size):
     """BASELINE configs 2 and 3 at their full sizes, on the reference's house_of_parliament mesh (its packed buffers travel inside
     the fixture) and on ours: HIP frame == multithreaded CPU oracle, every pixel."""
