@@ -138,38 +138,44 @@ __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16
     Axis ax = axis_setup(ray.o.x, ray.d.x, bh.tmin, bound.lo.x, bound.hi.x, n_slabs);
     Axis ay = axis_setup(ray.o.y, ray.d.y, bh.tmin, bound.lo.y, bound.hi.y, n_slabs);
     Axis az = axis_setup(ray.o.z, ray.d.z, bh.tmin, bound.lo.z, bound.hi.z, n_slabs);
-    float champ_t = ray.maxt, cb = 0.0f, cg = 0.0f, t = bh.tmin;
+    float champ_t = ray.maxt, cb = 0.0f, cg = 0.0f;
     uint32_t champ_i = UINT32_MAX;
     int hx = 0, hy = 0, hz = 0;
     const uint32_t zs = n_slabs * n_slabs, ys = n_slabs;
+    // phase A / phase B as in trace_dda (pt_trace.hpp): close and open cells until every live lane holds a triangle, then one test each
+    float t = bh.tmin, cmin = t, cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+    uint32_t cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
+    uint32_t i = slab_size[cell], end = slab_size[cell + 1];
     for (;;) {
-        const float cmin = t;
-        const float cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
-        const uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
-        const uint32_t begin = slab_size[cell], end = slab_size[cell + 1];
-        for (uint32_t i = begin; i < end; ++i) {
-            float ti, b, g;
-            bool hit = tri_test<TRI_A07, false>(ray.o, ray.d, cmin, cmax, prep[3u * i], prep[3u * i + 1], prep[3u * i + 2], ti, b, g);
-            if (hit && ti < champ_t) { champ_t = ti; champ_i = i; cb = b; cg = g; hx = ax.slab; hy = ay.slab; hz = az.slab; }
+        bool alive = true;
+        while (i == end) {
+            if (champ_i != UINT32_MAX) { alive = false; break; }
+            t = cmax;
+            if (t == ax.tnext) {
+                ax.tnext += ax.dt;
+                ax.slab += ax.dslab;
+                if (t >= bh.tmax || ax.slab == ax.limit) { alive = false; break; }
+            } else if (t == ay.tnext) {
+                ay.tnext += ay.dt;
+                ay.slab += ay.dslab;
+                if (t >= bh.tmax || ay.slab == ay.limit) { alive = false; break; }
+            } else {
+                az.tnext += az.dt;
+                az.slab += az.dslab;
+                if (t >= bh.tmax || az.slab == az.limit) { alive = false; break; }
+            }
+            cmin = t;
+            cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+            cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
+            i = slab_size[cell];
+            end = slab_size[cell + 1];
         }
-        if (champ_i != UINT32_MAX) break;
-        t = cmax;
-        if (t == ax.tnext) {
-            ax.tnext += ax.dt;
-            if (t >= bh.tmax) break;
-            ax.slab += ax.dslab;
-            if (ax.slab == ax.limit) break;
-        } else if (t == ay.tnext) {
-            ay.tnext += ay.dt;
-            if (t >= bh.tmax) break;
-            ay.slab += ay.dslab;
-            if (ay.slab == ay.limit) break;
-        } else {
-            az.tnext += az.dt;
-            if (t >= bh.tmax) break;
-            az.slab += az.dslab;
-            if (az.slab == az.limit) break;
-        }
+        if (!alive) break;
+        float ti, b, g;
+        const float4* __restrict__ p = prep + 3u * (size_t)i;
+        const bool hit = tri_test<TRI_A07, false>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, g);
+        if (hit && ti < champ_t) { champ_t = ti; champ_i = i; cb = b; cg = g; hx = ax.slab; hy = ay.slab; hz = az.slab; }
+        ++i;
     }
     if (champ_i == UINT32_MAX) return;
     rays[pix].maxt = champ_t;
