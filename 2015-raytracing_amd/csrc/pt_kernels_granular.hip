@@ -29,6 +29,35 @@ PT_DEV void store_dead(RayAoS* p) {  // code.cl:595, 647: only mint/maxt are def
     *reinterpret_cast<float2*>(reinterpret_cast<float4*>(p) + 2) = make_float2(PT_INF, PT_INF);
 }
 
+
+// ---- block-coalesced AoS output --------------------------------------------------------------------------------------------
+// The reference's work-item stores into its own Ray (48 B) / Poi (64 B): 16- and 8-byte pieces at a 48- or 64-byte lane stride,
+// and often only one field of the struct (maxt; atte; mint+maxt).  Measured on MI355X that costs a third of the kernel
+// (k_initShadowTrace 4.25 ms per 133 M rays as written by the work-items vs 2.91 ms below): partial sectors and three times the
+// write transactions.  Here the block's 256 consecutive structs -- one contiguous run of float4s -- are assembled in LDS and
+// written with unit-stride 16-byte stores.  `parts[struct]` says which of its float4s hold defined data (bit j = float4 j):
+// a struct the work-item would not have touched is not written, a field it would have left alone is either skipped (its float4
+// is masked out) or rewritten with the bits just loaded from it.  Pad words (.w of the float3s, the three ints after matId)
+// are written as zero; nothing reads them.  Used where a kernel WRITES whole rays (initTrace, bouncePaths, initShadowTrace, the
+// any-hit kernels, which now store nothing for a free ray).  Not used by k_closest (VALU-bound: 5.44 vs 5.51 ms) nor by
+// k_sceneRender (rewriting the whole 64-byte vertex instead of its 12-byte atte: 5.06 -> 5.49 ms).
+template <int F4>
+PT_DEV void flush_structs(const float4* lds, const uint8_t* parts, void* base, uint32_t first, uint32_t lim) {
+    __syncthreads();
+    const uint32_t count = first < lim ? (lim - first < 256u ? lim - first : 256u) : 0u;
+    float4* g = reinterpret_cast<float4*>(base) + (size_t)first * F4;
+    for (uint32_t k = threadIdx.x; k < count * F4; k += 256u)
+        if ((parts[k / F4] >> (k % F4)) & 1u) g[k] = lds[k];
+}
+PT_DEV void put_ray(float4* lds, const Ray& r) {
+    lds[3u * threadIdx.x] = make_float4(r.o.x, r.o.y, r.o.z, 0.0f);
+    lds[3u * threadIdx.x + 1] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
+    lds[3u * threadIdx.x + 2] = make_float4(r.mint, r.maxt, 0.0f, 0.0f);
+}
+PT_DEV void put_dead(float4* lds) { lds[3u * threadIdx.x + 2] = make_float4(PT_INF, PT_INF, 0.0f, 0.0f); }  // code.cl:595, 647: mint / maxt only
+constexpr uint8_t kRayAll = 7, kRayTail = 4;          // parts masks: the whole Ray / only {mint, maxt}
+constexpr uint8_t kPoiReset = 12;                  // Poi: atte + matId (initTrace)
+
 // code.cl:440-446
 __global__ void k_sizeofRay(uint32_t* out) { if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (uint32_t)sizeof(RayAoS); }
 __global__ void k_sizeofPoi(uint32_t* out) { if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = (uint32_t)sizeof(PoiAoS); }
@@ -60,60 +89,86 @@ __global__ void __launch_bounds__(64) k_lensDraws(int32_t* seeds, float2* uv, ui
     seeds[col] = s;
 }
 
-// code.cl:458-543.  One work-item per pixel, rays_per_pixel rays each.
+// code.cl:458-543.  The reference runs one work-item per pixel, which writes its rays_per_pixel rays and vertices one after the
+// other (neighbouring lanes rpp x 48 bytes apart).  Here: one thread per RAY, ids in buffer order, so a block's output is one
+// contiguous run.  The lens coordinates of sample (i, j) are rebuilt by the same repeated additions (coord += delta).
+// `wc` / `wr`: columns / rows the reference's NDRange would have covered (min(global size, image size)).
 __global__ void __launch_bounds__(256) k_initTrace(RayAoS* rays, PoiAoS* pois, const float2* uv, Box8 bound8, F16 cam16,
-                                                    float focal_length, float lens_rad, uint32_t rpp, uint32_t gx, uint32_t gy) {
+                                                    float focal_length, float lens_rad, uint32_t rpp, uint32_t wc, uint32_t wr) {
+    __shared__ float4 sray[256 * 3];
+    __shared__ float4 spoi[256 * 4];
+    __shared__ uint8_t pr[256], pq[256];
     const Cam cam = mk_cam(cam16);
-    const Box bound = mk_box(bound8);
-    uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t row = blockIdx.y * blockDim.y + threadIdx.y;
-    if (col >= gx || row >= gy) return;
-    if (col >= cam.cols || row >= cam.rows) return;
-    size_t base = ((size_t)cam.cols * row + col) * rpp;
-    f3 fp = focal_point(cam, (float)col, (float)row, focal_length);
-    if (rpp > 1) {
-        uint32_t side = f2u(cl_sqrt((float)rpp));
-        float delta = 1.0f / (float)side;
-        float cy = delta / 2.0f;
-        for (uint32_t i = 0; i < side; ++i) {
-            float cx = delta / 2.0f;
-            for (uint32_t j = 0; j < side; ++j) {
+    const uint64_t n_rays = (uint64_t)cam.cols * wr * rpp;
+    const uint64_t id = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    uint8_t mr = 0, mq = 0;
+    if (id < n_rays) {
+        const uint64_t pix = id / rpp;
+        const uint32_t smp = (uint32_t)(id - pix * rpp);
+        const uint32_t row = (uint32_t)(pix / cam.cols), col = (uint32_t)(pix - (uint64_t)row * cam.cols);
+        if (col < wc) {
+            const Box bound = mk_box(bound8);
+            f3 fp = focal_point(cam, (float)col, (float)row, focal_length);
+            bool have = true;
+            float cx, cy;
+            if (rpp > 1) {
+                const uint32_t side = f2u(cl_sqrt((float)rpp));
+                have = smp < side * side;             // rpp that is not a square: the k x k loops leave the tail rays unwritten
+                const float delta = 1.0f / (float)side;
+                const uint32_t i = side ? smp / side : 0u, j = smp - i * side;
+                cy = delta / 2.0f;
+                for (uint32_t k = 0; k < i; ++k) cy += delta;
+                cx = delta / 2.0f;
+                for (uint32_t k = 0; k < j; ++k) cx += delta;
+            } else {
+                float2 c = uv[(size_t)row * cam.cols + col];
+                cx = c.x;
+                cy = c.y;
+            }
+            if (have) {
                 Ray r = thin_lens_ray(cam, fp, lens_rad, cx, cy);
                 clip_to(r, bound);
-                store_ray(&rays[base + (size_t)i * side + j], r);
-                cx += delta;
+                put_ray(sray, r);
+                mr = kRayAll;
             }
-            cy += delta;
+            spoi[4u * threadIdx.x + 2] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            spoi[4u * threadIdx.x + 3] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
+            mq = kPoiReset;
         }
-    } else {
-        float2 c = uv[(size_t)row * cam.cols + col];
-        Ray r = thin_lens_ray(cam, fp, lens_rad, c.x, c.y);
-        clip_to(r, bound);
-        store_ray(&rays[base], r);
     }
-    for (uint32_t i = 0; i < rpp; ++i) {
-        PoiAoS* p = &pois[base + i];
-        p->ax = 1.0f; p->ay = 1.0f; p->az = 1.0f;
-        p->matId = -1;
-    }
+    pr[threadIdx.x] = mr;
+    pq[threadIdx.x] = mq;
+    const uint64_t first = (uint64_t)blockIdx.x * 256u;
+    const uint32_t lim32 = (uint32_t)(n_rays - first < 256u ? n_rays - first : 256u);
+    flush_structs<3>(sray, pr, reinterpret_cast<float4*>(rays) + first * 3u, 0u, first < n_rays ? lim32 : 0u);
+    flush_structs<4>(spoi, pq, reinterpret_cast<float4*>(pois) + first * 4u, 0u, first < n_rays ? lim32 : 0u);
 }
 
 // code.cl:581-598
 __global__ void __launch_bounds__(256) k_bouncePaths(const PoiAoS* pois, RayAoS* rays, int32_t* seeds, uint32_t total, uint32_t gsz) {
+    __shared__ float4 sray[256 * 3];
+    __shared__ uint8_t pr[256];
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= gsz || id >= total) return;
-    const PoiAoS* pp = &pois[id];
-    if (pp->matId >= 0) {
-        Poi poi;
-        poi.p = mk3(pp->px, pp->py, pp->pz);
-        poi.n = mk3(pp->nx, pp->ny, pp->nz);
-        int32_t s = seeds[id];
-        Ray r = bounce_ray(poi, s);
-        seeds[id] = s;
-        store_ray(&rays[id], r);
-    } else {
-        store_dead(&rays[id]);
+    const uint32_t lim = gsz < total ? gsz : total;
+    uint8_t mr = 0;
+    if (id < lim) {
+        const PoiAoS* pp = &pois[id];
+        if (pp->matId >= 0) {
+            Poi poi;
+            poi.p = mk3(pp->px, pp->py, pp->pz);
+            poi.n = mk3(pp->nx, pp->ny, pp->nz);
+            int32_t s = seeds[id];
+            Ray r = bounce_ray(poi, s);
+            seeds[id] = s;
+            put_ray(sray, r);
+            mr = kRayAll;
+        } else {
+            put_dead(sray);
+            mr = kRayTail;
+        }
     }
+    pr[threadIdx.x] = mr;
+    flush_structs<3>(sray, pr, rays, blockIdx.x * 256u, lim);
 }
 
 // code.cl:600-629
@@ -134,17 +189,29 @@ __global__ void __launch_bounds__(256) k_lightRender(PoiAoS* pois, RayAoS* rays,
 // code.cl:631-673
 __global__ void __launch_bounds__(256) k_initShadowTrace(RayAoS* shadow, const PoiAoS* pois, uint32_t total, F16 light,
                                                           int32_t* seeds, uint32_t gsz) {
+    __shared__ float4 sray[256 * 3];
+    __shared__ uint8_t pr[256];
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= gsz || id >= total) return;
-    const PoiAoS* pp = &pois[id];
-    if (pp->matId < 0) { store_dead(&shadow[id]); return; }
-    Poi poi;
-    poi.p = mk3(pp->px, pp->py, pp->pz);
-    poi.n = mk3(pp->nx, pp->ny, pp->nz);
-    int32_t s = seeds[id];
-    Ray r = shadow_ray(poi, ld3(light.v), ld3(light.v + 3), ld3(light.v + 6), light.v[9], s);
-    seeds[id] = s;
-    store_ray(&shadow[id], r);
+    const uint32_t lim = gsz < total ? gsz : total;
+    uint8_t mr = 0;
+    if (id < lim) {
+        const PoiAoS* pp = &pois[id];
+        if (pp->matId < 0) {
+            put_dead(sray);
+            mr = kRayTail;
+        } else {
+            Poi poi;
+            poi.p = mk3(pp->px, pp->py, pp->pz);
+            poi.n = mk3(pp->nx, pp->ny, pp->nz);
+            int32_t s = seeds[id];
+            Ray r = shadow_ray(poi, ld3(light.v), ld3(light.v + 3), ld3(light.v + 6), light.v[9], s);
+            seeds[id] = s;
+            put_ray(sray, r);
+            mr = kRayAll;
+        }
+    }
+    pr[threadIdx.x] = mr;
+    flush_structs<3>(sray, pr, shadow, blockIdx.x * 256u, lim);
 }
 
 // code.cl:675-800 (spheres), 802-935 (triangles, per-primitive material), 937-1070 (mesh, one material): one template,
@@ -191,16 +258,30 @@ __global__ void __launch_bounds__(256) k_closest(uint32_t total, PoiAoS* pois, R
 template <int KIND>
 __global__ void __launch_bounds__(256) k_anyhit(uint32_t total, RayAoS* shadow, const float4* prims, const uint32_t* off,
                                                  Box8 bound8, uint32_t n, uint32_t exit_far, uint32_t gsz) {
+    __shared__ float4 sray[256 * 3];
+    __shared__ uint8_t pr[256];
     uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= gsz || id >= total) return;
-    Ray sh = load_ray(&shadow[id]);
-    if (sh.mint == sh.maxt) return;
-    BoxHit bh = inter_aabb(sh, mk_box(bound8));
-    if (!bh.v) return;
-    bool unused = false;
-    Hit ch = trace_set<KIND, true>(sh, bh, mk_set(prims, off, bound8, n, exit_far), unused);
-    const float mint = (ch.idx != UINT32_MAX) ? ch.t : sh.mint;
-    *reinterpret_cast<float2*>(reinterpret_cast<float4*>(&shadow[id]) + 2) = make_float2(mint, ch.t);
+    const uint32_t lim = gsz < total ? gsz : total;
+    uint8_t mr = 0;
+    if (id < lim) {
+        Ray sh = load_ray(&shadow[id]);
+        if (!(sh.mint == sh.maxt)) {
+            BoxHit bh = inter_aabb(sh, mk_box(bound8));
+            if (bh.v) {
+                bool unused = false;
+                Hit ch = trace_set<KIND, true>(sh, bh, mk_set(prims, off, bound8, n, exit_far), unused);
+                // a free ray gets its own mint / maxt written back by the reference (code.cl:1186-1190): same bits, so nothing to store
+                if (ch.idx != UINT32_MAX) {
+                    sh.mint = ch.t;
+                    sh.maxt = ch.t;
+                    put_ray(sray, sh);
+                    mr = kRayAll;
+                }
+            }
+        }
+    }
+    pr[threadIdx.x] = mr;
+    flush_structs<3>(sray, pr, shadow, blockIdx.x * 256u, lim);
 }
 
 // code.cl:1323-1364.  `nmat` guards the material fetch: an out-of-range id (undefined
@@ -396,13 +477,17 @@ void launch_lensDraws(hipStream_t s, void* seeds, void* uv, uint32_t cols, uint3
 }
 void launch_initTrace(hipStream_t s, void* rays, void* pois, const void* uv, const float* bound, const float* cam,
                       float focal, float lens_rad, uint32_t rpp, uint32_t gx, uint32_t gy) {
-    if (!gx || !gy) return;
+    if (!gx || !gy || !rpp) return;
     Box8 b; F16 c;
     for (int i = 0; i < 8; ++i) b.v[i] = bound[i];
     for (int i = 0; i < 16; ++i) c.v[i] = cam[i];
-    dim3 blk(32, 8);
-    dim3 grd((gx + 31) / 32, (gy + 7) / 8);
-    hipLaunchKernelGGL(k_initTrace, grd, blk, 0, s, (RayAoS*)rays, (PoiAoS*)pois, (const float2*)uv, b, c, focal, lens_rad, rpp, gx, gy);
+    auto f2u_h = [](float f) -> uint32_t { return !(f == f) || f <= 0.0f ? 0u : f >= 4294967296.0f ? UINT32_MAX : (uint32_t)f; };   // = f2u() on the device
+    const uint32_t cols = f2u_h(cam[14]), rows = f2u_h(cam[15]);
+    const uint32_t wc = gx < cols ? gx : cols, wr = gy < rows ? gy : rows;
+    const uint64_t n_rays = (uint64_t)cols * wr * rpp;
+    if (!wc || !n_rays) return;
+    hipLaunchKernelGGL(k_initTrace, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, s, (RayAoS*)rays, (PoiAoS*)pois, (const float2*)uv, b, c, focal,
+                       lens_rad, rpp, wc, wr);
 }
 void launch_bouncePaths(hipStream_t s, const void* pois, void* rays, void* seeds, uint32_t total, uint32_t gsz) {
     if (!gsz) return;

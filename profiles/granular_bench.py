@@ -11,7 +11,7 @@ base = scene.PackedScene(open(os.path.join(ROOT, "tests", "golden", "scene_corne
 ctx = mirt.Context(0)
 # per sample: primary gen 84 B + lightRender 48 B + 6 segments x 568 B + 5 bounces x 128 B + resolve 20 B  
 BYTES = 84 + 48 + 6 * 568 + 5 * 128 + 20
-for rpp in (16, 64):
+for rpp in [int(x) for x in os.environ.get("RPPS", "16,64").split(",")]:
     sc = base.resized(1920, 1080, rpp)
     sc.cam = base.cam.copy()
     gr = render.GranularRenderer(ctx, sc)
