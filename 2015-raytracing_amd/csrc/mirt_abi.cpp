@@ -732,6 +732,13 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_render_pass: unknown context");
     if (!d || d->struct_size != sizeof(mirt_pass_desc)) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: descriptor size mismatch");
     if (!d->width || !d->height || !d->rays_per_pixel) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: empty image");
+    {   // the host only ever makes k x k rays per pixel (A10 code.js:540); initTrace's k x k loops leave the tail of any other count
+        // unwritten (code.cl:479-512), i.e. those rays would be whatever the buffer held -- there is nothing to reproduce
+        const uint32_t k = (uint32_t)std::sqrt((double)d->rays_per_pixel);
+        const uint32_t kk = (k + 1) * (k + 1) == d->rays_per_pixel ? k + 1 : k;
+        if (kk * kk != d->rays_per_pixel)
+            return fail(ctx, MIRT_E_ARG, "mirt_render_pass: rays_per_pixel %u is not a square (the lens grid is k x k, A10 code.js:540)", d->rays_per_pixel);
+    }
     if (d->n_lights > MIRT_MAX_LIGHTS) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: %u lights > %d (enqueue the kernels one by one instead)", d->n_lights, MIRT_MAX_LIGHTS);
     if (d->n_meshes > MIRT_MAX_MESHES) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: %u meshes > %d (enqueue the kernels one by one instead)", d->n_meshes, MIRT_MAX_MESHES);
     if ((d->n_lights && !d->lights) || (d->n_meshes && !d->meshes)) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: null light/mesh array");

@@ -162,6 +162,7 @@ typedef struct mirt_pass_desc {
     mirt_buf* radiance;             /* optional: float4 per local pixel, un-scaled sequential sums */
 } mirt_pass_desc;
 
+/* rays_per_pixel must be k*k, as the reference host makes it (A10 code.js:540): MIRT_E_ARG otherwise */
 MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
 /* Two ways to run the pass, identical results.  Default: the optimistic pair -- a kernel whose divisions are 3-operation
  * forms proven bit-exact inside a guard window (exhaustively, on the device: profiles/r1_divcheck_exhaustive.txt), plus the

@@ -139,6 +139,35 @@ def test_progressive_passes_match_oracle(ctx, pkg):
         fr.release()
 
 
+@pytest.mark.parametrize("rpp", [2, 5])
+def test_granular_pass_with_a_non_square_ray_count(ctx, pkg, rpp):
+    """The host always asks for k x k rays per pixel (A10 code.js:540), but the kernels take any count: initTrace's k x k loops write
+    the first k*k rays of a pixel and leave the rest as the buffer held them (code.cl:479-512) while resetting ALL rpp vertices.
+    With zeroed buffers on both sides the tail rays are dead (mint == maxt == 0) and the whole pass is defined: kernel-by-kernel HIP
+    == oracle.  The fused pass refuses such a count."""
+    from raytracing_amd.pyhost import mirt, render
+    fx, sc0 = load_fixture("cornell_32x24_r4")
+    sc = A.Scene(dict(sc0.d, rays_per_pixel=rpp))
+    seeds = A.make_seeds(sc.total_rays)
+    orc = A.load_oracle()
+    st = A.PassState(sc, seeds)
+    A.run_pass(orc, sc, st)
+    gr = render.GranularRenderer(ctx, sc, seeds=seeds)
+    for name in ("rays", "pois", "shadow"):
+        ctx.zero(gr.b[name])
+    gr.execute_render()
+    got = snapshot(gr)
+    assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds)
+    assert np.array_equal(got["pois"]["matId"], st.pois["matId"])
+    for f in ("mint", "maxt"):
+        assert np.array_equal(bits(got["rays"][f]), bits(st.rays[f]))
+    assert np.array_equal(gr.read("pixel").reshape(-1, 4), st.pixel)
+    gr.release()
+    with pytest.raises(mirt.MirtError) as e:
+        render.FusedRenderer(ctx, sc, seeds=seeds).execute_render()
+    assert e.value.code == -1 and "not a square" in str(e.value)
+
+
 def test_full_size_properties(ctx, pkg):
     """BASELINE config 4 geometry at 1920x1080 (rpp 4 to keep the test short): size-independent properties.
     (1) the 1080p frame's top-left 64x48 window... is NOT comparable (camera differs), so instead:
