@@ -70,11 +70,9 @@ PT_DEV Cam mk_cam(const F16& f) {
 // remainder.  For an int32 x, x % (2^31-1) is x itself except at three values.
 PT_DEV int32_t lcg_next(int32_t s) {
     int32_t w = (int32_t)((uint32_t)s * 16807u);
-    int32_t r = w;
-    r = (w == INT32_MAX) ? 0 : r;
-    r = (w == -INT32_MAX) ? 0 : r;
-    r = (w == INT32_MIN) ? -1 : r;
-    return r;
+    // the three values are one unsigned range [0x7FFFFFFF, 0x80000001] = {INT32_MAX, INT32_MIN, -INT32_MAX}: one compare, a rare fix-up
+    if (__builtin_expect((uint32_t)w - 0x7FFFFFFFu <= 2u, 0)) w = (w == INT32_MIN) ? -1 : 0;
+    return w;
 }
 PT_DEV float lcg_float(int32_t s) { return cl_fabs((float)s * 4.656612873077392578125e-10f); }  // * 2^-31
 PT_DEV float get_rand(int32_t& seed) { seed = lcg_next(seed); return lcg_float(seed); }

@@ -345,6 +345,28 @@ __global__ void __launch_bounds__(64) k_copyToPixel(uchar4* pixel, const float4*
     if (pixel) pixel[id] = make_uchar4((unsigned char)f2u(c.x), (unsigned char)f2u(c.y), (unsigned char)f2u(c.z), 255);
 }
 
+// rpp <= 4 (the page's default is 1: progressive passes): a pixel's samples span at most one 64-byte sector, so the work-item
+// walk of the reference is already coalesced -- no staging, 256-thread blocks (k_copyToPixel at rpp 1: 67 us per 1080p frame,
+// this: see profiles/README.md)
+__global__ void __launch_bounds__(256) k_copyToPixelSmall(uchar4* pixel, const float4* acu, float m, uint32_t pixels, uint32_t rpp,
+                                                           uint32_t gsz, float4* radiance) {
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lim = pixels < gsz ? pixels : gsz;
+    if (id >= lim) return;
+    float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4* a = acu + (size_t)id * rpp;
+    for (uint32_t s = 0; s < rpp; ++s) {
+        const float4 v = a[s];
+        c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;
+    }
+    if (radiance) radiance[id] = c;
+    float sc = 255.0f * m;
+    c.x = cl_clamp((c.x * sc) * 1.8f, 0.0f, 255.0f);
+    c.y = cl_clamp((c.y * sc) * 1.8f, 0.0f, 255.0f);
+    c.z = cl_clamp((c.z * sc) * 1.8f, 0.0f, 255.0f);
+    if (pixel) pixel[id] = make_uchar4((unsigned char)f2u(c.x), (unsigned char)f2u(c.y), (unsigned char)f2u(c.z), 255);
+}
+
 // splitmix32-style seed fill: s[id] = 1 + (mix(id ^ 0x9E3779B9 ^ base) mod 2147483646), ids global
 // (SURVEY 8d config 4); the reference seeds with Math.random() on the host (A10 code.js:1140-1146).
 __global__ void __launch_bounds__(256) k_seedFill(int32_t* seeds, uint64_t first, uint64_t count, uint32_t base) {
@@ -530,6 +552,10 @@ void launch_sceneRender(hipStream_t s, void* acu, void* pois, const void* shadow
 }
 void launch_copyToPixel(hipStream_t s, void* pixel, const void* acu, float m, uint32_t pixels, uint32_t rpp, uint32_t gsz, void* radiance) {
     if (!gsz) return;
+    if (rpp <= 4u) {
+        hipLaunchKernelGGL(k_copyToPixelSmall, grid1(gsz), dim3(256), 0, s, (uchar4*)pixel, (const float4*)acu, m, pixels, rpp, gsz, (float4*)radiance);
+        return;
+    }
     hipLaunchKernelGGL(k_copyToPixel, grid1(gsz, 64), dim3(64), 0, s, (uchar4*)pixel, (const float4*)acu, m, pixels, rpp, gsz, (float4*)radiance);
 }
 void launch_numerics(hipStream_t s, int op, const void* a, const void* b, void* out, uint64_t n) {
