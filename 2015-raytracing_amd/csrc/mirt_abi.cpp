@@ -46,9 +46,7 @@ struct mirt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* defer = nullptr;        // optimistic pass: [count, cursor, pad, pad | mask words...]
     size_t defer_bytes = 0;
-    void* defer_list = nullptr;
-    size_t defer_list_bytes = 0;
-    uint64_t last_deferred = 0;   // samples the last mirt_render_pass handed to the exact kernel
+    uint32_t defer_words = 0;     // mask words the last mirt_render_pass used (0: it ran the exact kernel only)
     int force_exact = 0;          // mirt_ctx_set_exact_only: 1 = skip the optimistic kernel, run every sample through the exact one
     bool profiling = false;       // per-kernel events inside mirt_render_pass
     hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
@@ -286,7 +284,6 @@ int mirt_ctx_destroy(mirt_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->defer) (void)hipFree(ctx->defer);
-    if (ctx->defer_list) (void)hipFree(ctx->defer_list);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& e : ctx->pe) if (e) (void)hipEventDestroy(e);
@@ -790,9 +787,9 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->pe[0], ctx->stream));
     bool optimistic = pt::fused_fast_available() && !ctx->force_exact;
     for (uint32_t i = 0; i < A.n_sets; ++i) optimistic = optimistic && A.sets[i].fast_ok != 0;
-    ctx->last_deferred = 0;
     if (optimistic) {
-        // optimistic kernel (exact cheap divisions inside their window) + exact kernel for the samples that left the window
+        // optimistic kernel (exact cheap divisions inside their window) + exact kernel over the samples that left the window:
+        // the second launch walks the first one's bit mask on the device, so the pair is queued without a host round trip
         const uint32_t words = (uint32_t)((nrays + 31) / 32);
         const size_t need_bytes = 16 + (size_t)words * 4;
         if (ctx->defer_bytes < need_bytes) {
@@ -800,26 +797,14 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
             HIPCHK(ctx, hipMalloc(&ctx->defer, need_bytes));
             ctx->defer_bytes = need_bytes;
         }
-        uint32_t* counters = (uint32_t*)ctx->defer;
-        uint32_t* mask = counters + 4;
+        uint32_t* mask = (uint32_t*)ctx->defer + 4;
         HIPCHK(ctx, hipMemsetAsync(ctx->defer, 0, need_bytes, ctx->stream));
         pt::launch_fused(ctx->stream, A, true, mask, nullptr, 0);
-        pt::launch_deferCount(ctx->stream, mask, words, counters);
-        uint32_t count = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&count, counters, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->last_deferred = count;
-        if (count) {
-            if (ctx->defer_list_bytes < (size_t)count * 4) {
-                if (ctx->defer_list) { HIPCHK(ctx, hipFree(ctx->defer_list)); ctx->defer_list = nullptr; ctx->defer_list_bytes = 0; }
-                HIPCHK(ctx, hipMalloc(&ctx->defer_list, (size_t)count * 4));
-                ctx->defer_list_bytes = (size_t)count * 4;
-            }
-            pt::launch_deferList(ctx->stream, mask, words, counters + 1, (uint32_t*)ctx->defer_list);
-            pt::launch_fused(ctx->stream, A, false, nullptr, (const uint32_t*)ctx->defer_list, count);
-        }
+        pt::launch_fused(ctx->stream, A, false, nullptr, mask, words);
+        ctx->defer_words = words;
     } else {
         pt::launch_fused(ctx->stream, A, false, nullptr, nullptr, 0);
+        ctx->defer_words = 0;
     }
     if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->pe[1], ctx->stream));
     if (d->pixel || d->radiance) {
@@ -843,7 +828,17 @@ int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on) {
 int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_pass_deferred: unknown context");
     if (!samples) return fail(ctx, MIRT_E_ARG, "mirt_pass_deferred: null output");
-    *samples = ctx->last_deferred;
+    *samples = 0;
+    if (!ctx->defer_words) return MIRT_OK;
+    // counted on demand: the mask of the last pass is still in place (the next pass clears it)
+    uint32_t* counters = (uint32_t*)ctx->defer;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(counters, 0, 16, ctx->stream));
+    pt::launch_deferCount(ctx->stream, counters + 4, ctx->defer_words, counters);
+    uint32_t count = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&count, counters, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *samples = count;
     return MIRT_OK;
 }
 

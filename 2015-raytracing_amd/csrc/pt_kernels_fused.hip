@@ -194,13 +194,19 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 #define PT_FUSED_WAVES_GRIDS 6
 #endif
 template <bool FAST, bool GRIDS>
-__global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES)) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count) {
+__global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES)) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words) {
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;
-    uint64_t lid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (!FAST && list) {
-        if (lid >= list_count) return;
-        lid = list[lid];
+    // Exact kernel in redo mode (`redo_mask`: the bits the optimistic kernel set): one thread per 32-sample word, a loop over its
+    // set bits -- no list, no count, no host round trip between the two kernels.  Otherwise: one thread, one sample, one trip.
+    uint64_t base = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t todo = 1u;
+    if (!FAST && redo_mask) {
+        if (base >= redo_words) return;
+        todo = redo_mask[base];
+        base *= 32u;
     }
+  for (; todo; todo &= todo - 1u) {
+    const uint64_t lid = base + (uint32_t)__builtin_ctz(todo);
     if (lid >= n_local) return;
     bool defer = false;
     const uint64_t lpix = lid / A.rpp;
@@ -295,26 +301,18 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     acc = make_float4(park.get(0), park.get(1), park.get(2), park.get(3));
 #endif
     ((float4*)A.acu)[lid] = acc;
+  }
 }
 
-// deferred-sample bookkeeping: count the set bits, then expand them into a dense list for k_fusedPass<false>
+// deferred-sample bookkeeping: count the set bits (only when the host asks, mirt_pass_deferred)
 __global__ void __launch_bounds__(256) k_deferCount(const uint32_t* mask, uint32_t words, uint32_t* count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t c = (i < words) ? (uint32_t)__builtin_popcount(mask[i]) : 0u;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
-__global__ void __launch_bounds__(256) k_deferList(const uint32_t* mask, uint32_t words, uint32_t* cursor, uint32_t* list) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= words) return;
-    uint32_t w = mask[i];
-    if (!w) return;
-    uint32_t at = atomicAdd(cursor, (uint32_t)__builtin_popcount(w));
-    while (w) { const int b = __builtin_ctz(w); list[at++] = i * 32u + (uint32_t)b; w &= w - 1; }
-}
-
-void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count) {
-    const uint64_t n = list ? list_count : (uint64_t)a.nrows * a.width * a.rpp;
+void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words) {
+    const uint64_t n = redo_mask ? redo_words : (uint64_t)a.nrows * a.width * a.rpp;
     if (!n) return;
     bool grids = false;
     for (uint32_t i = 0; i < a.n_sets; ++i) grids = grids || a.sets[i].n != 1u;
@@ -323,16 +321,13 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
         if (grids) hipLaunchKernelGGL((k_fusedPass<true, true>), grid, dim3(256), 0, s, a, defer_mask, (const uint32_t*)nullptr, 0u);
         else hipLaunchKernelGGL((k_fusedPass<true, false>), grid, dim3(256), 0, s, a, defer_mask, (const uint32_t*)nullptr, 0u);
     } else {
-        if (grids) hipLaunchKernelGGL((k_fusedPass<false, true>), grid, dim3(256), 0, s, a, (uint32_t*)nullptr, list, list_count);
-        else hipLaunchKernelGGL((k_fusedPass<false, false>), grid, dim3(256), 0, s, a, (uint32_t*)nullptr, list, list_count);
+        if (grids) hipLaunchKernelGGL((k_fusedPass<false, true>), grid, dim3(256), 0, s, a, (uint32_t*)nullptr, redo_mask, redo_words);
+        else hipLaunchKernelGGL((k_fusedPass<false, false>), grid, dim3(256), 0, s, a, (uint32_t*)nullptr, redo_mask, redo_words);
     }
 }
 bool fused_fast_available() { return PT_EXACT_FAST_DIV != 0; }
 void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count) {
     if (words) hipLaunchKernelGGL(k_deferCount, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, count);
-}
-void launch_deferList(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* cursor, uint32_t* list) {
-    if (words) hipLaunchKernelGGL(k_deferList, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, cursor, list);
 }
 
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word) {

@@ -69,10 +69,9 @@ struct FusedArgs {
     const void* uv;          // rpp == 1: float2[nrows*width] lens draws from launch_lensDraws
 };
 // fast: the optimistic kernel (writes deferred samples' bits into defer_mask); !fast: the exact kernel over `list` (or everything)
-void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* list, uint32_t list_count);
+void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words);
 bool fused_fast_available();   // compiled with PT_EXACT_FAST_DIV
 void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count);
-void launch_deferList(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* cursor, uint32_t* list);
 // {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip)
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word);
 

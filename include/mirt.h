@@ -168,8 +168,9 @@ MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
  * forms proven bit-exact inside a guard window (exhaustively, on the device: profiles/r1_divcheck_exhaustive.txt), plus the
  * exact kernel re-running the samples whose rays left the window (NaN rays, axis-parallel directions, ...); it needs every
  * grid to pass the geometry-side window check, otherwise the pass silently is the exact one.  mirt_ctx_set_exact_only(ctx, 1):
- * one kernel whose every division is the compiler's correctly rounded expansion.  mirt_pass_deferred: how many samples the
- * last pass re-ran through the exact kernel. */
+ * one kernel whose every division is the compiler's correctly rounded expansion.  The pair is queued without a host round trip
+ * (the exact kernel walks the optimistic kernel's bit mask on the device).  mirt_pass_deferred: how many samples the last pass
+ * re-ran through the exact kernel -- counted when asked (one small launch + a stream sync), valid until the next pass. */
 MIRT_API int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples);
 MIRT_API int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on);
 
