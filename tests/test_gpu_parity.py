@@ -168,6 +168,53 @@ def test_granular_pass_with_a_non_square_ray_count(ctx, pkg, rpp):
     assert e.value.code == -1 and "not a square" in str(e.value)
 
 
+def _variant(sc0, **kw):
+    """The same packed scene with fields replaced; width / height changes re-pack the camera the way Camera.lookAt does."""
+    d = dict(sc0.d)
+    w, h = kw.pop("width", d["width"]), kw.pop("height", d["height"])
+    cam = list(d["cam"])
+    cam[12] = float(np.float32(cam[13] * (w / h)))
+    cam[14], cam[15] = float(w), float(h)
+    d.update(cam=cam, width=w, height=h, **kw)
+    return A.Scene(d)
+
+
+DEGENERATE = {
+    "no_lights": lambda sc: _variant(sc, lights=[]),                                            # nothing is ever shaded; paths still bounce
+    "no_geometry": lambda sc: _variant(sc, n_spheres=0, n_triangles=0, meshes=[]),              # every ray misses everything
+    "spheres_only_ragged_13x7": lambda sc: _variant(sc, n_triangles=0, meshes=[], width=13, height=7),   # image not a multiple of any block
+    "one_pixel": lambda sc: _variant(sc, width=1, height=1),
+    "one_column_rpp1": lambda sc: _variant(sc, width=1, height=9, rays_per_pixel=1),            # the seeds[col] stream feeds every row
+    "tall_sliver_2x67": lambda sc: _variant(sc, width=2, height=67),
+}
+
+
+@pytest.mark.parametrize("case", sorted(DEGENERATE))
+def test_degenerate_scenes_match_oracle(ctx, pkg, case):
+    """Empty and ragged inputs: no lights, no primitives, image sizes that fill no block / wave / 8x8 work-group, a single pixel, a single
+    column at rpp 1.  Both HIP paths against the oracle on the same seeds."""
+    from raytracing_amd.pyhost import render
+    fx, sc0 = load_fixture("cornell_teapot3_32x24_r4")
+    sc = DEGENERATE[case](sc0)
+    seeds = A.make_seeds(sc.total_rays)
+    orc = A.load_oracle()
+    st = A.PassState(sc, seeds)
+    A.run_pass(orc, sc, st)
+    gr = render.GranularRenderer(ctx, sc, seeds=seeds)
+    gr.execute_render()
+    got = snapshot(gr)
+    assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds), "granular"
+    assert np.array_equal(got["pois"]["matId"], st.pois["matId"])
+    assert np.array_equal(gr.read("pixel").reshape(-1, 4), st.pixel)
+    gr.release()
+    fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+    fr.execute_render()
+    assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(st.acu)), "fused"
+    assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
+    assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), st.pixel)
+    fr.release()
+
+
 def test_full_size_properties(ctx, pkg):
     """BASELINE config 4 geometry at 1920x1080 (rpp 4 to keep the test short): size-independent properties.
     (1) the 1080p frame's top-left 64x48 window... is NOT comparable (camera differs), so instead:
