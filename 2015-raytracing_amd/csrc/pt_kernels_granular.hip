@@ -220,7 +220,7 @@ PT_DEV GridArgs mk_set(const float4* prims, const uint32_t* off, const Box8& b, 
     GridArgs S;
     S.prims = prims; S.normals = nullptr; S.matid = nullptr; S.off = off;
     for (int i = 0; i < 8; ++i) S.bound[i] = b.v[i];
-    S.n = n; S.mesh_matid = 0; S.kind = 0; S.fast_ok = 0; S.exit_is_far_face = exit_far;
+    S.n = n; S.mesh_matid = 0; S.kind = 0; S.fast_ok = 0; S.lds_off = kNoLds; S.exit_is_far_face = exit_far;
     return S;
 }
 template <int KIND>

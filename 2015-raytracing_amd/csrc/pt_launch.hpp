@@ -33,6 +33,8 @@ void launch_seedFill(hipStream_t s, void* seeds, uint64_t first, uint64_t count,
 constexpr int kMaxLights = 8;
 constexpr int kMaxMeshes = 16;
 
+constexpr uint32_t kNoLds = 0xFFFFFFFFu;
+constexpr uint32_t kLdsOffWords = 4096;   // 16 KB of LDS per block for cell-offset tables (n <= 15 for a single grid)
 struct GridArgs {            // one cell-sorted primitive set, device pointers
     const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per PREPARED triangle (launch_prepTriangles)
     const void* normals;     // 3 x float4 per triangle (null for spheres)
@@ -44,6 +46,8 @@ struct GridArgs {            // one cell-sorted primitive set, device pointers
     uint32_t kind;           // KIND_SPHERES | KIND_TRIANGLES
     uint32_t fast_ok;        // geometry-side guard of the exact 3-operation divisions (pt_trace.hpp ray_recip): every bound is 0 or
                              // in [2^-30, 2^20]; for triangles every plane-normal component is 0 or in [2^-40, 2^40]
+    uint32_t lds_off;        // n > 1, fused pass: dword index of this set's cell-offset table inside the block's LDS copy, or
+                             // kNoLds when the tables of the scene do not fit (launch_fused assigns it)
     uint32_t exit_is_far_face; // n == 1 only: lo + 1*((hi-lo)/1) == hi and lo + 0*((hi-lo)/1) == lo hold bitwise on all three
                              // axes (checked on the host), so the single cell's exit t equals the AABB slab's far t
 };

@@ -205,9 +205,13 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
 
 // trace_dda: n > 1, per-lane 3-axis DDA.
 template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false>
-PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer) {
+PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer, const uint32_t* lds_tables = nullptr) {
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
+    // cell -> [begin, end): from the block's LDS copy of the table when the fused pass staged one (a step of the walk then waits
+    // on an LDS read instead of a vector-memory round trip), else from memory
+    const bool staged = lds_tables != nullptr && S.lds_off != kNoLds;
+    const uint32_t* lt = lds_tables + (staged ? S.lds_off : 0u);
     Hit ch;
     ch.idx = UINT32_MAX;
     ch.t = ray.maxt;
@@ -229,7 +233,8 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     float cmin = t;
     float cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
     uint32_t cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
-    uint32_t i = off[cell], end = off[cell + 1];
+    uint32_t i, end;
+    if (staged) { i = lt[cell]; end = lt[cell + 1]; } else { i = off[cell]; end = off[cell + 1]; }
     for (;;) {
         bool alive = true;
         while (i == end) {
@@ -254,8 +259,7 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
             cmin = t;
             cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
             cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
-            i = off[cell];
-            end = off[cell + 1];
+            if (staged) { i = lt[cell]; end = lt[cell + 1]; } else { i = off[cell]; end = off[cell + 1]; }
         }
         if (!alive) break;
         float ti, b = 0.0f, gm = 0.0f;
