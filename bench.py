@@ -41,7 +41,7 @@ PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r1d_park_lds: FETCH_SIZE x 2 + WRITE_SIZE,
 # KiB -> bytes; gfx950 halves FETCH_SIZE on wide coalesced reads, MI355X_MICROARCH.md).  Valid for the default workload only.
-TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 10.62e9, "write_bytes": 10.62e9, "source": "profiles/r1g_depth8/pmc_summary.json"}
+TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 10.62e9, "write_bytes": 10.62e9, "source": "profiles/r1i_final/pmc_summary.json"}
 
 
 def cpu_baseline(packed_json, log, bounces):
