@@ -12,6 +12,10 @@ __global__ void __launch_bounds__(256) k(float* out, float sv, int n) {
     float a[8];
     for (int i = 0; i < 8; ++i) a[i] = out[(threadIdx.x + i * 64) & 1023] + (float)i;
     unsigned long long m = 0;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p[5];
+    for (int i = 0; i < 5; ++i) { p[i].x = a[i]; p[i].y = a[(i + 3) & 7]; }
+    f2 sp; sp.x = sv; sp.y = sv * 1.5f;
     for (int it = 0; it < n; ++it) {
         if (KIND == 0) { R16(asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %2, %2, %1\n v_mul_f32 %3, %3, %1\n v_mul_f32 %4, %4, %1" : "+v"(a[0]), "+v"(a[4]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) :: );) }
         if (KIND == 1) { R16(asm volatile("v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %2, %2, %1, %2\n v_fma_f32 %3, %3, %1, %3\n v_fma_f32 %4, %4, %1, %4" : "+v"(a[0]), "+v"(a[4]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) :: );) }
@@ -22,9 +26,15 @@ __global__ void __launch_bounds__(256) k(float* out, float sv, int n) {
         if (KIND == 6) { R16(asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(a[4]) : );) }
         if (KIND == 7) { R16(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_lt_f32 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "vcc");) }
         if (KIND == 8) { R16(asm volatile("v_sub_f32 %0, %0, %1\n v_add_f32 %2, %2, %1\n v_sub_f32 %3, %3, %1\n v_add_f32 %4, %4, %1" : "+v"(a[0]), "+v"(a[4]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) :: );) }
+        if (KIND == 9) { R16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(p[4]) : );) }
+        if (KIND == 10) { R16(asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(p[4]) : );) }
+        if (KIND == 11) { R16(asm volatile("v_pk_fma_f32 %0, %0, %4, %0\n v_pk_fma_f32 %1, %1, %4, %1\n v_pk_fma_f32 %2, %2, %4, %2\n v_pk_fma_f32 %3, %3, %4, %3" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(p[4]) : );) }
+        if (KIND == 12) { R16(asm volatile("v_pk_mul_f32 %0, %0, %4 op_sel_hi:[1,0]\n v_pk_mul_f32 %1, %1, %4 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %2, %4 op_sel_hi:[1,0]\n v_pk_mul_f32 %3, %3, %4 op_sel_hi:[1,0]" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(p[4]) : );) }
+        if (KIND == 13) { R16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "s"(sp) : );) }
         m += (unsigned long long)it;
     }
     float s = 0; for (int i = 0; i < 8; ++i) s += a[i];
+    for (int i = 0; i < 5; ++i) s += p[i].x + p[i].y;
     if (s == 12345.678f) out[0] = s + (float)m;
 }
 template <int KIND> double run(float* d, int waves_per_simd) {
@@ -47,7 +57,8 @@ int main() {
         printf("waves/SIMD %d:", w);
         printf(" mul %.2f", run<0>(d, w)); printf(" fma %.2f", run<1>(d, w)); printf(" mul_s %.2f", run<2>(d, w)); printf(" cmp_s %.2f", run<3>(d, w));
         printf(" cndmask_s %.2f", run<4>(d, w)); printf(" rcp %.2f", run<5>(d, w)); printf(" mul_lo %.2f", run<6>(d, w)); printf(" cmp+cnd_vcc %.2f", run<7>(d, w));
-        printf(" addsub %.2f\n", run<8>(d, w));
+        printf(" addsub %.2f", run<8>(d, w));
+        printf(" | pk_mul %.2f pk_add %.2f pk_fma %.2f pk_mul_opsel %.2f pk_mul_sgpr %.2f\n", run<9>(d, w), run<10>(d, w), run<11>(d, w), run<12>(d, w), run<13>(d, w));
     }
     (void)names;
     return 0;
