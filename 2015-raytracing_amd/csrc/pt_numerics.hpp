@@ -21,7 +21,7 @@
                               // rays leave the guard window to k_fusedPass<EXACT>; 0: only the exact kernel runs
 #endif
 #ifndef PT_EXACT_FAST_NORM
-#define PT_EXACT_FAST_NORM 0  // normalize(): per-lane guarded refined reciprocal (a zero-length vector must still give 1/0)
+#define PT_EXACT_FAST_NORM 1  // normalize(): per-lane guarded refined reciprocal (a zero-length vector must still give 1/0); 226.1 -> 223.7 ms
 #endif
 
 namespace pt {

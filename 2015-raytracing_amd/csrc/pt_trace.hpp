@@ -65,9 +65,20 @@ PT_DEV bool ray_guard(const Ray& r) {
     auto owin = [](float o) { return o == 0.0f || (__builtin_fabsf(o) >= 9.3132257e-10f && __builtin_fabsf(o) <= 1048576.0f); };  // 0 | 2^-30 .. 2^20
     return dwin(r.d.x) && dwin(r.d.y) && dwin(r.d.z) && owin(r.o.x) && owin(r.o.y) && owin(r.o.z);
 }
+// SIGNED_ZERO = false: a zero numerator may come back as a zero of either sign (the two selects of div_exact3 are dropped).  Allowed
+// where tmin / tmax / the exit t are only ever COMPARED (the single-cell loops: cmin <= t <= cmax); the grid walk feeds tmin into
+// x = o + tmin*d and keeps the exact quotient.
+template <bool SIGNED_ZERO>
 PT_DEV bool slab1_fast(float lo, float hi, float o, float d, float r, BoxHit& h, float& tfar) {
-    float t0 = div_exact3(lo - o, d, r);
-    float t1 = div_exact3(hi - o, d, r);
+    float t0, t1;
+    if (SIGNED_ZERO) {
+        t0 = div_exact3(lo - o, d, r);
+        t1 = div_exact3(hi - o, d, r);
+    } else {
+        const float n0 = lo - o, n1 = hi - o, q0 = n0 * r, q1 = n1 * r;
+        t0 = __builtin_fmaf(__builtin_fmaf(-d, q0, n0), r, q0);
+        t1 = __builtin_fmaf(__builtin_fmaf(-d, q1, n1), r, q1);
+    }
     const bool neg = d < 0;
     float tn = neg ? t1 : t0;
     float tf = neg ? t0 : t1;
@@ -77,16 +88,16 @@ PT_DEV bool slab1_fast(float lo, float hi, float o, float d, float r, BoxHit& h,
     return !(h.tmin > h.tmax);
 }
 // inter_aabb (pt_device.hpp); FAST: the six slab quotients share three refined reciprocals
-template <bool FAST>
+template <bool FAST, bool SIGNED_ZERO = true>
 PT_DEV BoxHit inter_aabb_t(const Ray& r, const Box& b) {
     if (FAST) {
         BoxHit h;
         h.tmin = 0.0f;
         h.tmax = PT_INF;
         const float rx = rcp_refined(r.d.x), ry = rcp_refined(r.d.y), rz = rcp_refined(r.d.z);
-        const bool okx = slab1_fast(b.lo.x, b.hi.x, r.o.x, r.d.x, rx, h, h.tfx);
-        const bool oky = slab1_fast(b.lo.y, b.hi.y, r.o.y, r.d.y, ry, h, h.tfy);
-        const bool okz = slab1_fast(b.lo.z, b.hi.z, r.o.z, r.d.z, rz, h, h.tfz);
+        const bool okx = slab1_fast<SIGNED_ZERO>(b.lo.x, b.hi.x, r.o.x, r.d.x, rx, h, h.tfx);
+        const bool oky = slab1_fast<SIGNED_ZERO>(b.lo.y, b.hi.y, r.o.y, r.d.y, ry, h, h.tfy);
+        const bool okz = slab1_fast<SIGNED_ZERO>(b.lo.z, b.hi.z, r.o.z, r.d.z, rz, h, h.tfz);
         h.v = okx && oky && okz;
         return h;
     }
