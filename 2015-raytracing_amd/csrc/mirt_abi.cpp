@@ -1007,7 +1007,7 @@ int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, 
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_divcheck: unknown context");
     int rc = need(ctx, "mirt_debug_divcheck out", out16, 16 * 8);
     if (rc) return rc;
-    if (mode < 0 || mode > 4) return fail(ctx, MIRT_E_ARG, "mirt_debug_divcheck: mode is 0..4");
+    if (mode < 0 || mode > 5) return fail(ctx, MIRT_E_ARG, "mirt_debug_divcheck: mode is 0..5");
     if (mode == 4 && (seed > (1u << 23) || count > (1u << 23) - seed)) return fail(ctx, MIRT_E_ARG, "mirt_debug_divcheck: mode 4 walks denominators [seed, seed+count) within 2^23 mantissas");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(out16->ptr, 0, 16 * 8, ctx->stream));

@@ -429,6 +429,23 @@ __global__ void __launch_bounds__(256) k_divCheck(int mode, uint64_t seed, uint6
         if (m1) { atomicAdd(&out[1], m1); atomicMin(&out[10], lo); atomicMax(&out[11], hi); }
         return;
     }
+    if (mode == 5) {
+        // every one of the 2^32 bit patterns: cl_sqrt (the 9-operation core + denormal fallback) against the compiler's correctly rounded
+        // sqrt, and the bare core alone (out[2]: it may differ only inside (0, 2^-96), out[3] counts the others); out[1] = cl_sqrt mismatches
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+            const float x = __uint_as_float((uint32_t)i);
+            const float want = __builtin_sqrtf(x), got = cl_sqrt(x), core = sqrt_core(x);
+            if (!((__float_as_uint(got) == __float_as_uint(want)) || (got != got && want != want))) { ++m1; atomicMin(&out[10], (unsigned long long)i); atomicMax(&out[11], (unsigned long long)i); out[4] = __float_as_uint(got); out[5] = __float_as_uint(want); }
+            if (!((__float_as_uint(core) == __float_as_uint(want)) || (core != core && want != want))) {
+                ++m2;
+                if (!(__builtin_fabsf(x) > 0.0f && __builtin_fabsf(x) < 1.2621774e-29f)) ++m3;   // a core mismatch with |x| OUTSIDE (0, 2^-96) would break the claim
+            }
+        }
+        if (m1) atomicAdd(&out[1], m1);
+        if (m2) atomicAdd(&out[2], m2);
+        if (m3) atomicAdd(&out[3], m3);
+        return;
+    }
     if (mode == 4) {
         // EVERY mantissa pair: d = 1.dm, n = 1.nm, dm in [seed, seed + count), nm in [0, 2^23).  Powers of two scale every
         // step of div_exact3 exactly while nothing leaves the normal range (the windows guarantee that) and rcp_refined is

@@ -34,7 +34,34 @@ PT_DEV float cl_fmin(float x, float y) { return __builtin_fminf(x, y); }
 PT_DEV float cl_fmax(float x, float y) { return __builtin_fmaxf(x, y); }
 PT_DEV float cl_clamp(float x, float lo, float hi) { return cl_fmin(cl_fmax(x, lo), hi); }
 PT_DEV float cl_fabs(float x) { return __builtin_fabsf(x); }
-PT_DEV float cl_sqrt(float x) { return __builtin_sqrtf(x); }
+// Correctly rounded sqrt.  hipcc expands __builtin_sqrtf into: scale denormal inputs up (3 ops), v_sqrt_f32 (1 ulp), try the two
+// neighbours s -+ 1 ulp against the residual (8 ops), scale back (2), patch 0 / inf by class (2).  The scaling exists because the
+// residual fma(-s', s, x) underflows for small x; hipcc scales below 2^-96.  For every input with |x| outside (0, 2^-96) the 9-operation core
+// alone returns the same bits -- 0, -0, inf, NaN and negatives included: the neighbour of 0 or inf is a NaN or a denormal whose
+// residual test fails, so the v_sqrt result stands (checked on the device over all 2^32 bit patterns, mirt_debug_divcheck mode 5:
+// the bare core differs from IEEE on 20.7 M patterns, every one of them with 0 < |x| < 2^-96 -- small positives, and the negative
+// denormals, which v_sqrt_f32 flushes to -0 instead of answering NaN).  Those take the compiler's sequence.
+#ifndef PT_EXACT_FAST_SQRT
+#define PT_EXACT_FAST_SQRT 1
+#endif
+PT_DEV float sqrt_core(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
+    float r = (rdn <= 0.0f) ? dn : s;
+    r = (rup > 0.0f) ? up : r;
+    return r;
+}
+PT_DEV float cl_sqrt(float x) {
+#if PT_EXACT_FAST_SQRT
+    float r = sqrt_core(x);
+    const float ax = __builtin_fabsf(x);
+    if (__builtin_expect(ax > 0.0f && ax < 1.2621774e-29f, 0)) r = __builtin_sqrtf(x);   // 0 < |x| < 2^-96 (hipcc's own scaling threshold): rare lanes only
+    return r;
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
 PT_DEV float cl_mad(float a, float b, float c) { return a * b + c; }
 
 // float -> int the way v_cvt_i32_f32 does it (truncate, saturate, NaN -> 0), spelled

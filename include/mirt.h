@@ -212,7 +212,8 @@ MIRT_API int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b
 /* counts mismatches between the shared-reciprocal division forms of pt_numerics.hpp and the compiler's correctly
  * rounded division over `count` generated (n, d) pairs; `out16` receives 16 uint64 (see k_divCheck).
  * mode 0/1/2: random pairs inside the windows; 3: all 2^32 denominators of the reciprocal; 4: every numerator mantissa
- * against the `count` denominator mantissas starting at `seed` (2^23 launches' worth covers all 2^46 pairs) */
+ * against the `count` denominator mantissas starting at `seed` (2^23 launches' worth covers all 2^46 pairs); 5: the 9-operation
+ * correctly rounded sqrt over all 2^32 bit patterns (out[1] mismatches of cl_sqrt, out[2] / out[3] of the bare core / outside denormals) */
 MIRT_API int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16);
 
 /* ---- measurement: HIP events on the context's stream ---------------------------------- */

@@ -117,6 +117,10 @@ def test_cheap_exact_division_forms(ctx):
         assert int(r[1]) == 0 and int(r[2]) == 0
         if mode == 2:
             assert int(r[0]) == 0 and int(r[3]) == 0       # without +-0 numerators even the bare forms agree
+    # the 9-operation sqrt: every bit pattern; the bare core may only differ from IEEE inside (0, 2^-96), where cl_sqrt falls back
+    r = ctx.divcheck(5, 0, 1 << 32)
+    assert int(r[1]) == 0, f"cl_sqrt differs from the correctly rounded sqrt on {int(r[1])} bit patterns"
+    assert int(r[3]) == 0 and int(r[2]) < 31 * 2**23
     # a slice of the exhaustive mantissa-pair sweep (all 2^46 pairs: profiles/divcheck.py --exhaustive, result under profiles/)
     for first in (0, 0x400000, 0x7FFF00):
         r = ctx.divcheck(4, first, 256)
