@@ -78,6 +78,15 @@ PT_DEV bool slab1_fast(float lo, float hi, float o, float d, float r, BoxHit& h,
         const float n0 = lo - o, n1 = hi - o, q0 = n0 * r, q1 = n1 * r;
         t0 = __builtin_fmaf(__builtin_fmaf(-d, q0, n0), r, q0);
         t1 = __builtin_fmaf(__builtin_fmaf(-d, q1, n1), r, q1);
+        // Inside the guard windows both quotients are finite (no NaN), and correctly rounded division is monotonic, so "the plane
+        // the ray meets first" (d < 0 ? t1 : t0) IS min(t0, t1) and the other one max(t0, t1); OpenCL's min / max select forms then
+        // agree with v_min_f32 / v_max_f32 up to the sign of a zero, which nothing downstream can see (compare-only).  Six full-rate
+        // instructions instead of three compares and six selects per slab pair... per box: 12 instead of 21 half-rate ones.
+        const float tn = __builtin_fminf(t0, t1), tf = __builtin_fmaxf(t0, t1);
+        tfar = tf;
+        h.tmin = __builtin_fmaxf(tn, h.tmin);
+        h.tmax = __builtin_fminf(tf, h.tmax);
+        return !(h.tmin > h.tmax);
     }
     const bool neg = d < 0;
     float tn = neg ? t1 : t0;
@@ -185,7 +194,8 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         }
     }
     const float cmin = bh.tmin;
-    const float cmax = cl_min(cl_min(tn[0], tn[1]), tn[2]);
+    // FAST: finite operands, result only compared -> one v_min3_f32 (see slab1_fast)
+    const float cmax = FAST ? __builtin_fminf(__builtin_fminf(tn[0], tn[1]), tn[2]) : cl_min(cl_min(tn[0], tn[1]), tn[2]);
     const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
     const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
     bool done = false;
