@@ -252,7 +252,8 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     const uint32_t zs = S.n * S.n, ys = S.n;   // n <= 1024 (check_grid): 24-bit multiplies are exact
     float t = bh.tmin;
     float cmin = t;
-    float cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+    // FAST: the three exits are finite and the minimum is only compared (== against them, <= against t): one v_min3_f32
+    float cmax = FAST ? __builtin_fminf(__builtin_fminf(ax.tnext, ay.tnext), az.tnext) : cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
     uint32_t cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
     uint32_t i, end;
     if (staged) { i = lt[cell]; end = lt[cell + 1]; } else { i = off[cell]; end = off[cell + 1]; }
@@ -278,7 +279,7 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
                 if (t >= bh.tmax || az.slab == az.limit) { alive = false; break; }
             }
             cmin = t;
-            cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
+            cmax = FAST ? __builtin_fminf(__builtin_fminf(ax.tnext, ay.tnext), az.tnext) : cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
             cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
             if (staged) { i = lt[cell]; end = lt[cell + 1]; } else { i = off[cell]; end = off[cell + 1]; }
         }
