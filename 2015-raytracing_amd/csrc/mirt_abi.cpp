@@ -721,6 +721,10 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
         const float a = std::fabs(g->bounds[k]);
         if (!(a == 0.0f || (a >= 9.3132257e-10f && a <= 1048576.0f))) o->fast_ok = 0;
     }
+    // the optimistic kernel's box test takes min / max of the two plane quotients as near / far: that needs lo <= hi on every axis
+    // (an inverted box is a miss in the reference; here it goes to the exact kernel)
+    for (int k = 0; k < 3; ++k)
+        if (!(g->bounds[k] <= g->bounds[4 + k])) o->fast_ok = 0;
     if (tri && !g->prims->prep_sane) o->fast_ok = 0;
     return MIRT_OK;
 }

@@ -186,6 +186,8 @@ DEGENERATE = {
     "one_pixel": lambda sc: _variant(sc, width=1, height=1),
     "one_column_rpp1": lambda sc: _variant(sc, width=1, height=9, rays_per_pixel=1),            # the seeds[col] stream feeds every row
     "tall_sliver_2x67": lambda sc: _variant(sc, width=2, height=67),
+    # an inverted box (min > max on one axis) is a miss for every ray in the reference; the optimistic kernel must not see it
+    "inverted_sphere_box": lambda sc: _variant(sc, meshes=[], sphere_bounds=[b if i != 0 and i != 4 else sc.d["sphere_bounds"][4 - i] for i, b in enumerate(sc.d["sphere_bounds"])]),
 }
 
 
