@@ -26,7 +26,7 @@
 #include "pt_trace.hpp"
 
 #ifndef PT_AABB_UNSIGNED_ZERO
-#define PT_AABB_UNSIGNED_ZERO 1   // GRIDS = false only: see slab1_fast
+#define PT_AABB_UNSIGNED_ZERO 1   // single-cell sets only (their tmin / tmax / exits are compare-only): see slab1_fast
 #endif
 
 namespace pt {
@@ -91,11 +91,11 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
         ch.idx = UINT32_MAX;
         if (!GRIDS || S.n == 1u) {
             if (live) {
-                const BoxHit bh = inter_aabb_t<FAST, GRIDS || !PT_AABB_UNSIGNED_ZERO>(ray, set_box(S));
+                const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(ray, set_box(S));
                 if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, false, TRI_A10, FAST>(ray, bh, S) : trace_cell1<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S);
             }
         } else if (live) {
-            const BoxHit bh = inter_aabb_t<FAST, GRIDS || !PT_AABB_UNSIGNED_ZERO>(ray, set_box(S));
+            const BoxHit bh = inter_aabb_t<FAST, true>(ray, set_box(S));
             if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, false, TRI_A10, FAST>(ray, bh, S, defer, tables) : trace_dda<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S, defer, tables);
         }
         if (ch.idx == UINT32_MAX) continue;
@@ -143,14 +143,14 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             bool walked = false;
             if (!GRIDS || S.n == 1u) {
                 if (live) {
-                    const BoxHit bh = inter_aabb_t<FAST, GRIDS || !PT_AABB_UNSIGNED_ZERO>(sh, set_box(S));
+                    const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(sh, set_box(S));
                     if (bh.v) {
                         ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, true, TRI_A10, FAST>(sh, bh, S) : trace_cell1<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S);
                         walked = true;
                     }
                 }
             } else if (live) {
-                const BoxHit bh = inter_aabb_t<FAST, GRIDS || !PT_AABB_UNSIGNED_ZERO>(sh, set_box(S));
+                const BoxHit bh = inter_aabb_t<FAST, true>(sh, set_box(S));
                 if (bh.v) {
                     ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, true, TRI_A10, FAST>(sh, bh, S, defer, tables) : trace_dda<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S, defer, tables);
                     walked = true;
