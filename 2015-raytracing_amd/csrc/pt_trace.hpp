@@ -22,6 +22,9 @@ struct Hit { uint32_t idx; float t, beta, gamma; };
 // TRI_A10: closed t interval, no gamma > 1 test (A10 code.cl:273, 280)
 // TRI_A07: open t interval, no gamma > 1 test   (A07 code.cl:188, 195)
 // TRI_A04: open t interval, gamma > 1 rejects    (A04 code.cl:170, 177)
+#ifndef PT_GUARD_INT
+#define PT_GUARD_INT 1
+#endif
 enum TriRule { TRI_A10 = 0, TRI_A07 = 1, TRI_A04 = 2 };
 // FAST: 1/div by the 3-operation refined reciprocal (pt_numerics.hpp), exact whenever div is zero or inside its window, which
 // the guards guarantee (ray_guard() on the ray side, GridArgs::fast_ok on the geometry side).  A lane whose ray fails the guard
@@ -61,9 +64,22 @@ PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const f
 //     multiple of 2^-103)                                                     -> rcp_refined == the true reciprocal
 //   * dot(d,d) is in [2^-80, 2^82]                                            -> the sphere's 1/(2a) likewise
 PT_DEV bool ray_guard(const Ray& r) {
+#if PT_GUARD_INT
+    // the same windows on the bit patterns: for |x| the unsigned order of the bits is the order of the values, NaN and inf sort above
+    // every finite value, and "zero or >= lo" is (bits - 1) >= (lo_bits - 1) in unsigned arithmetic.  Two 3-way minima, two 3-way maxima
+    // and four compares instead of eighteen compares.
+    auto ab = [](float x) { return __float_as_uint(x) & 0x7FFFFFFFu; };
+    auto umin3 = [](uint32_t a, uint32_t b, uint32_t c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); };
+    auto umax3 = [](uint32_t a, uint32_t b, uint32_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); };
+    const uint32_t dx = ab(r.d.x), dy = ab(r.d.y), dz = ab(r.d.z), ox = ab(r.o.x), oy = ab(r.o.y), oz = ab(r.o.z);
+    const uint32_t dlo = umin3(dx, dy, dz), dhi = umax3(dx, dy, dz);
+    const uint32_t olo = umin3(ox - 1u, oy - 1u, oz - 1u), ohi = umax3(ox, oy, oz);
+    return ((int)(dlo >= 0x2B800000u) & (int)(dhi <= 0x53800000u) & (int)(olo >= 0x30800000u - 1u) & (int)(ohi <= 0x49800000u)) != 0;   // 2^-40, 2^40, 2^-30, 2^20
+#else
     auto dwin = [](float d) { return __builtin_fabsf(d) >= 9.094947e-13f && __builtin_fabsf(d) <= 1.0995116e12f; };          // 2^-40 .. 2^40
     auto owin = [](float o) { return o == 0.0f || (__builtin_fabsf(o) >= 9.3132257e-10f && __builtin_fabsf(o) <= 1048576.0f); };  // 0 | 2^-30 .. 2^20
     return dwin(r.d.x) && dwin(r.d.y) && dwin(r.d.z) && owin(r.o.x) && owin(r.o.y) && owin(r.o.z);
+#endif
 }
 // SIGNED_ZERO = false: a zero numerator may come back as a zero of either sign (the two selects of div_exact3 are dropped).  Allowed
 // where tmin / tmax / the exit t are only ever COMPARED (the single-cell loops: cmin <= t <= cmax); the grid walk feeds tmin into
