@@ -55,8 +55,8 @@ PT_DEV float sqrt_core(float x) {
 PT_DEV float cl_sqrt(float x) {
 #if PT_EXACT_FAST_SQRT
     float r = sqrt_core(x);
-    const float ax = __builtin_fabsf(x);
-    if (__builtin_expect(ax > 0.0f && ax < 1.2621774e-29f, 0)) r = __builtin_sqrtf(x);   // 0 < |x| < 2^-96 (hipcc's own scaling threshold): rare lanes only
+    // 0 < |x| < 2^-96 (hipcc's own scaling threshold), as ONE unsigned compare on the bits of |x|: zero wraps to the top, NaN / inf sit above
+    if (__builtin_expect((__float_as_uint(x) & 0x7FFFFFFFu) - 1u < 0x0F800000u - 1u, 0)) r = __builtin_sqrtf(x);   // rare lanes only
     return r;
 #else
     return __builtin_sqrtf(x);
@@ -107,7 +107,7 @@ PT_DEV float div_exact3(float n, float d, float r) {
     float q = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0);
     return (n == 0.0f) ? q0 : q;
 }
-PT_DEV bool rcp_window(float x) { return __builtin_fabsf(x) >= 1.17549435e-38f && __builtin_fabsf(x) < 8.5070592e37f; }   // normal, < 2^126
+PT_DEV bool rcp_window(float x) { return (__float_as_uint(x) & 0x7FFFFFFFu) - 0x00800000u < 0x7E800000u - 0x00800000u; }   // normal, < 2^126 (one unsigned compare)
 // 1.0f/x, bit for bit.  `dont_care`: lanes whose result is never used (they must not force the slow path).
 PT_DEV float rcp_exact(float x, bool dont_care = false) {
 #if PT_EXACT_FAST_DIV && PT_EXACT_FAST_NORM
