@@ -217,6 +217,32 @@ def test_degenerate_scenes_match_oracle(ctx, pkg, case):
     fr.release()
 
 
+def test_headline_frame_two_exact_routes_agree(ctx, pkg):
+    """BASELINE config 4 at its full size and depth (1920x1080, 256 rays per pixel, 8 bounces = 531 M samples): the default pair
+    (optimistic kernel with every hand-written exact form -- 3-operation quotients, refined reciprocals, 9-operation sqrt, min/max box
+    test -- plus the exact kernel for the deferred samples) against the single exact kernel, whose divisions and roots are the
+    compiler's.  Per-pixel fp32 sums, RGBA8 and every ray's final seed must be identical."""
+    import os
+    from raytracing_amd.pyhost import render, scene
+    from conftest import GOLDEN
+    sc = scene.PackedScene(open(os.path.join(GOLDEN, "scene_cornell_1920x1080_r256.json")).read())
+    out = []
+    for exact_only in (False, True):
+        ctx.set_exact_only(exact_only)
+        try:
+            fr = render.FusedRenderer(ctx, sc, want_radiance=True)
+            fr.execute_render(bounces=8)
+            deferred = ctx.pass_deferred()
+            out.append((fr.radiance.read(np.float32), fr.pixel.read(np.uint8), fr.seeds.read(np.int32), deferred))
+            fr.release()
+        finally:
+            ctx.set_exact_only(False)
+    (r0, p0, s0, d0), (r1, p1, s1, d1) = out
+    assert d1 == 0 and 0 < d0 < 10000                      # a few hundred samples per frame leave the guard windows
+    assert np.array_equal(bits(r0), bits(r1)) and np.array_equal(p0, p1) and np.array_equal(s0, s1)
+    assert (p0.reshape(-1, 4)[:, :3].max(axis=1) > 0).mean() > 0.9
+
+
 def test_full_size_properties(ctx, pkg):
     """BASELINE config 4 geometry at 1920x1080 (rpp 4 to keep the test short): size-independent properties.
     (1) the 1080p frame's top-left 64x48 window... is NOT comparable (camera differs), so instead:
