@@ -51,6 +51,13 @@ struct mirt_ctx {
     bool profiling = false;       // per-kernel events inside mirt_render_pass
     hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
     bool pe_valid = false;
+    bool capturing = false;       // between mirt_capture_begin and mirt_capture_end: the stream records, nothing may wait on it
+};
+
+struct mirt_graph {
+    mirt_ctx* ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 struct mirt_buf {
@@ -159,6 +166,10 @@ uint32_t f2u_host(float f) {
     return (uint32_t)f;
 }
 
+// operations that wait on the stream or move host memory cannot be part of a recording
+#define NOT_WHILE_CAPTURING(ctx, what) \
+    do { if ((ctx)->capturing) return fail((ctx), MIRT_E_ARG, "%s is not possible inside mirt_capture_begin/end: run the sequence once before recording it", (what)); } while (0)
+
 int need(mirt_ctx* ctx, const char* what, const mirt_buf* b, uint64_t bytes) {
     if (!live_has(b)) return fail(ctx, MIRT_E_HANDLE, "%s: released or unknown buffer", what);
     if (b->ctx != ctx) return fail(ctx, MIRT_E_ARG, "%s: buffer belongs to another context", what);
@@ -176,6 +187,7 @@ int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const
     int rc = need(ctx, what, off, (cells + 1) * 4);
     if (rc) return rc;
     if (!(off->off_version == off->version && off->off_n == n)) {
+        NOT_WHILE_CAPTURING(ctx, "validating a new cell-offset table");
         std::vector<uint32_t> h(cells + 1);
         HIPCHK(ctx, hipMemcpyAsync(h.data(), off->ptr, (cells + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -213,6 +225,7 @@ uint32_t exit_is_far_face(const float* b8, uint32_t n) {
 int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
     const size_t bytes = (size_t)count * 48;
     if (pb->prep_version == pb->version && pb->prep_bytes >= bytes && (pb->prep || !bytes)) return MIRT_OK;
+    NOT_WHILE_CAPTURING(ctx, "preparing a new triangle buffer");
     if (pb->prep) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pb->prep)); pb->prep = nullptr; pb->prep_bytes = 0; }
     if (bytes) { HIPCHK(ctx, hipMalloc(&pb->prep, bytes)); pb->prep_bytes = bytes; }
     int rc = ensure_scratch(ctx, 16);
@@ -229,6 +242,7 @@ int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
 
 int ensure_scratch(mirt_ctx* ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return MIRT_OK;
+    NOT_WHILE_CAPTURING(ctx, "growing the scratch buffer");
     if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
     HIPCHK(ctx, hipMalloc(&ctx->scratch, bytes));
     ctx->scratch_bytes = bytes;
@@ -300,6 +314,7 @@ const char* mirt_last_error(mirt_ctx* ctx) {
 
 int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_stream: unknown context");
+    NOT_WHILE_CAPTURING(ctx, "mirt_ctx_set_stream");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return MIRT_OK;
@@ -307,6 +322,7 @@ int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream) {
 
 int mirt_finish(mirt_ctx* ctx) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_finish: unknown context");
+    NOT_WHILE_CAPTURING(ctx, "mirt_finish");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MIRT_OK;
@@ -363,6 +379,7 @@ int mirt_buf_write(mirt_buf* buf, size_t offset, size_t nbytes, const void* host
     (void)blocking;
     if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_write: unknown buffer");
     mirt_ctx* ctx = buf->ctx;
+    NOT_WHILE_CAPTURING(ctx, "mirt_buf_write");
     if (!host && nbytes) return fail(ctx, MIRT_E_ARG, "mirt_buf_write: null host pointer");
     if (offset > buf->bytes || nbytes > buf->bytes - offset)
         return fail(ctx, MIRT_E_RANGE, "mirt_buf_write: [%zu, +%zu) exceeds buffer of %zu bytes", offset, nbytes, buf->bytes);
@@ -378,6 +395,7 @@ int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* host, int b
     (void)blocking;
     if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_read: unknown buffer");
     mirt_ctx* ctx = buf->ctx;
+    NOT_WHILE_CAPTURING(ctx, "mirt_buf_read");
     if (!host && nbytes) return fail(ctx, MIRT_E_ARG, "mirt_buf_read: null host pointer");
     if (offset > buf->bytes || nbytes > buf->bytes - offset)
         return fail(ctx, MIRT_E_RANGE, "mirt_buf_read: [%zu, +%zu) exceeds buffer of %zu bytes", offset, nbytes, buf->bytes);
@@ -788,7 +806,7 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
         pt::launch_lensDraws(ctx->stream, A.seeds, ctx->scratch, d->width, d->height, d->width, d->height, d->row0, nrows);
         A.uv = ctx->scratch;
     }
-    if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->pe[0], ctx->stream));
+    if (ctx->profiling && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->pe[0], ctx->stream));
     bool optimistic = pt::fused_fast_available() && !ctx->force_exact;
     for (uint32_t i = 0; i < A.n_sets; ++i) optimistic = optimistic && A.sets[i].fast_ok != 0;
     if (optimistic) {
@@ -797,6 +815,7 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
         const uint32_t words = (uint32_t)((nrays + 31) / 32);
         const size_t need_bytes = 16 + (size_t)words * 4;
         if (ctx->defer_bytes < need_bytes) {
+            NOT_WHILE_CAPTURING(ctx, "growing the deferred-sample mask");
             if (ctx->defer) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->defer)); ctx->defer = nullptr; ctx->defer_bytes = 0; }
             HIPCHK(ctx, hipMalloc(&ctx->defer, need_bytes));
             ctx->defer_bytes = need_bytes;
@@ -810,13 +829,13 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
         pt::launch_fused(ctx->stream, A, false, nullptr, nullptr, 0);
         ctx->defer_words = 0;
     }
-    if (ctx->profiling) HIPCHK(ctx, hipEventRecord(ctx->pe[1], ctx->stream));
+    if (ctx->profiling && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->pe[1], ctx->stream));
     if (d->pixel || d->radiance) {
         const float m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
         pt::launch_copyToPixel(ctx->stream, d->pixel ? d->pixel->ptr : nullptr, A.acu, m, (uint32_t)npix, A.rpp, (uint32_t)npix,
                                d->radiance ? d->radiance->ptr : nullptr);
     }
-    if (ctx->profiling) { HIPCHK(ctx, hipEventRecord(ctx->pe[2], ctx->stream)); ctx->pe_valid = true; }
+    if (ctx->profiling && !ctx->capturing) { HIPCHK(ctx, hipEventRecord(ctx->pe[2], ctx->stream)); ctx->pe_valid = true; }
     HIPCHK(ctx, hipGetLastError());
     d->seeds->version++;
     d->acu->version++;
@@ -831,6 +850,7 @@ int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on) {
 
 int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_pass_deferred: unknown context");
+    NOT_WHILE_CAPTURING(ctx, "mirt_pass_deferred");
     if (!samples) return fail(ctx, MIRT_E_ARG, "mirt_pass_deferred: null output");
     *samples = 0;
     if (!ctx->defer_words) return MIRT_OK;
@@ -1021,14 +1041,69 @@ int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, 
     return MIRT_OK;
 }
 
+int mirt_capture_begin(mirt_ctx* ctx) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_capture_begin: unknown context");
+    if (ctx->capturing) return fail(ctx, MIRT_E_ARG, "mirt_capture_begin: already recording");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = true;
+    return MIRT_OK;
+}
+
+int mirt_capture_end(mirt_ctx* ctx, mirt_graph** out) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_capture_end: unknown context");
+    if (!out) return fail(ctx, MIRT_E_ARG, "mirt_capture_end: null output");
+    if (!ctx->capturing) return fail(ctx, MIRT_E_ARG, "mirt_capture_end: not recording");
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        return fail(ctx, MIRT_E_DEVICE, "mirt_capture_end: the recording was invalidated (%s)", hipGetErrorString(e));
+    }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fail(ctx, MIRT_E_DEVICE, "mirt_capture_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    mirt_graph* mg = new mirt_graph;
+    mg->ctx = ctx; mg->graph = g; mg->exec = x;
+    live_add(mg);
+    *out = mg;
+    return MIRT_OK;
+}
+
+int mirt_graph_launch(mirt_ctx* ctx, mirt_graph* graph) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_graph_launch: unknown context");
+    if (!live_has(graph) || graph->ctx != ctx) return fail(ctx, MIRT_E_HANDLE, "mirt_graph_launch: unknown graph");
+    NOT_WHILE_CAPTURING(ctx, "mirt_graph_launch");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipGraphLaunch(graph->exec, ctx->stream));
+    return MIRT_OK;
+}
+
+int mirt_graph_release(mirt_graph* graph) {
+    if (!live_has(graph)) return fail(nullptr, MIRT_E_HANDLE, "mirt_graph_release: unknown graph");
+    mirt_ctx* ctx = graph->ctx;
+    if (live_has(ctx)) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGraphExecDestroy(graph->exec);
+    (void)hipGraphDestroy(graph->graph);
+    live_del(graph);
+    delete graph;
+    return MIRT_OK;
+}
+
 int mirt_timer_start(mirt_ctx* ctx) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_timer_start: unknown context");
+    NOT_WHILE_CAPTURING(ctx, "mirt_timer_start");
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return MIRT_OK;
 }
 
 int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_timer_stop_ms: unknown context");
+    NOT_WHILE_CAPTURING(ctx, "mirt_timer_stop_ms");
     if (!ms) return fail(ctx, MIRT_E_ARG, "mirt_timer_stop_ms: null output");
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));

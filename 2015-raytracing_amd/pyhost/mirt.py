@@ -91,6 +91,10 @@ SYMBOLS = {
     "mirt_grid_gather_spheres": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mirt_grid_gather_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mirt_debug_divcheck": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "mirt_capture_begin": (C.c_int, [C.c_void_p]),
+    "mirt_capture_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mirt_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mirt_graph_release": (C.c_int, [C.c_void_p]),
     "mirt_debug_numerics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
@@ -220,6 +224,21 @@ class Context:
 
     def zero(self, buf):
         self._chk(lib().mirt_zero(self.h, buf.h))
+
+    # launch-bound sequences as HIP graphs (mirt.h "launch-bound sequences")
+    def capture_begin(self):
+        self._chk(lib().mirt_capture_begin(self.h))
+
+    def capture_end(self):
+        g = C.c_void_p()
+        self._chk(lib().mirt_capture_end(self.h, C.byref(g)))
+        return g
+
+    def graph_launch(self, g):
+        self._chk(lib().mirt_graph_launch(self.h, g))
+
+    def graph_release(self, g):
+        lib().mirt_graph_release(g)
 
     def timer_start(self):
         self._chk(lib().mirt_timer_start(self.h))

@@ -136,10 +136,11 @@ class GranularRenderer:
                 k["triangleShadowTrace"].set_arg(2, m["prims"]).set_arg(3, m["off"]).set_arg(4, m["bounds"]).set_arg(5, _u32(m["n"]))
                 k["triangleShadowTrace"].enqueue(self.g1, [64])
             k["sceneRender"].set_arg(4, l["scene"]).enqueue(self.g1, [64])  # executeSceneRender (code.js:1402-1408)
-            self.ctx.finish()
+            if not getattr(self, "_recording", False):   # the reference finishes the queue here (code.js:1406); a recording cannot wait
+                self.ctx.finish()
 
     # -- executeRender (code.js:1806-1854)
-    def execute_render(self, bounces=5, on_primary=None):
+    def _enqueue_segments(self, bounces, on_primary=None):
         s, k = self.s, self.k
         k["initTrace"].set_arg(4, s.cam).enqueue(self.gws["initTrace"], self.lws["initTrace"])
         self._closest()
@@ -152,6 +153,27 @@ class GranularRenderer:
             k["bouncePaths"].enqueue(self.g1, [64])
             self._closest()
             self._direct()
+
+    def execute_render(self, bounces=5, on_primary=None, use_graph=False):
+        """One executeRender() (code.js:1806-1854).  use_graph: the 40-odd enqueues of the pass body are recorded once (on the second
+        pass; the first one runs normally and fills the runtime's caches) and replayed as one HIP graph afterwards; copyToPixel stays
+        outside because its scale argument changes every pass (code.js:1412)."""
+        s, k = self.s, self.k
+        if use_graph and on_primary is None and self.passes > 1:
+            if getattr(self, "_graph", None) is None or self._graph_bounces != bounces:
+                if getattr(self, "_graph", None) is not None:
+                    self.ctx.graph_release(self._graph)
+                self.ctx.capture_begin()
+                self._recording = True
+                try:
+                    self._enqueue_segments(bounces)
+                finally:
+                    self._recording = False
+                    self._graph = self.ctx.capture_end()
+                self._graph_bounces = bounces
+            self.ctx.graph_launch(self._graph)
+        else:
+            self._enqueue_segments(bounces, on_primary)
         div = np.float32(1.0 / (s.rpp * self.passes))  # executeCopyToPixel (code.js:1410-1415)
         k["copyToPixel"].set_arg(2, _f32(div)).enqueue(self.gws["copyToPixel"], [64])
         self.ctx.finish()
@@ -162,6 +184,9 @@ class GranularRenderer:
         return self.b[name].read(from_dt[name])
 
     def release(self):
+        if getattr(self, "_graph", None) is not None:
+            self.ctx.graph_release(self._graph)
+            self._graph = None
         for k in self.k.values():
             k.release()
         for b in self.b.values():

@@ -216,6 +216,19 @@ MIRT_API int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b
  * correctly rounded sqrt over all 2^32 bit patterns (out[1] mismatches of cl_sqrt, out[2] / out[3] of the bare core / outside denormals) */
 MIRT_API int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16);
 
+/* ---- launch-bound sequences as HIP graphs ------------------------------------------------------
+ * The reference's executeRender() is 44+ enqueues per pass (A10 code.js:1806-1854); on a 320x240 canvas at one ray per pixel (the
+ * page's defaults, index.html:46, code.js:400) every one of them is a few microseconds of work behind a launch.  Between
+ * mirt_capture_begin and mirt_capture_end every mirt_enqueue / mirt_render_pass / mirt_zero / mirt_seed_fill on the context is
+ * recorded instead of run; mirt_graph_launch replays the recording with the argument values it was recorded with.  Run the sequence
+ * once normally first: whatever needs a host round trip (cell-table validation, triangle preparation, scratch growth) is cached
+ * by that run and refused (MIRT_E_ARG) inside a capture, as are mirt_finish, buffer reads / writes and timers. */
+typedef struct mirt_graph mirt_graph;
+MIRT_API int mirt_capture_begin(mirt_ctx* ctx);
+MIRT_API int mirt_capture_end(mirt_ctx* ctx, mirt_graph** out);
+MIRT_API int mirt_graph_launch(mirt_ctx* ctx, mirt_graph* graph);
+MIRT_API int mirt_graph_release(mirt_graph* graph);
+
 /* ---- measurement: HIP events on the context's stream ---------------------------------- */
 MIRT_API int mirt_timer_start(mirt_ctx* ctx);
 MIRT_API int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms);   /* synchronises */

@@ -168,6 +168,33 @@ def test_granular_pass_with_a_non_square_ray_count(ctx, pkg, rpp):
     assert e.value.code == -1 and "not a square" in str(e.value)
 
 
+@pytest.mark.parametrize("name", ["cornell_64x48_r1", "cornell_teapot3_32x24_r4"])
+def test_graph_replayed_passes_match_oracle(ctx, pkg, name):
+    """Five progressive passes of the kernel-by-kernel path; from the third pass on the pass body is a HIP graph replay
+    (mirt_capture_begin / end / mirt_graph_launch).  rpp 1 has the serial lens pre-pass inside initTrace; the teapot scene has per-mesh
+    argument changes between launches -- both are recorded by value."""
+    from raytracing_amd.pyhost import mirt, render
+    fx, sc = load_fixture(name)
+    orc = A.load_oracle()
+    st = A.PassState(sc, fx["seeds_in"])
+    gr = render.GranularRenderer(ctx, sc, seeds=fx["seeds_in"])
+    for p in range(5):
+        A.run_pass(orc, sc, st, init_acu=(p == 0))
+        gr.execute_render(use_graph=True)
+        got = snapshot(gr)
+        assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds), f"pass {p}"
+        assert np.array_equal(gr.read("pixel").reshape(-1, 4), st.pixel), f"pixel, pass {p}"
+    assert gr._graph is not None
+    # what cannot be recorded says so, and the recording survives it
+    ctx.capture_begin()
+    with pytest.raises(mirt.MirtError) as e:
+        ctx.finish()
+    assert e.value.code == -1 and "capture" in str(e.value)
+    g = ctx.capture_end()
+    ctx.graph_release(g)
+    gr.release()
+
+
 def _variant(sc0, **kw):
     """The same packed scene with fields replaced; width / height changes re-pack the camera the way Camera.lookAt does."""
     d = dict(sc0.d)
