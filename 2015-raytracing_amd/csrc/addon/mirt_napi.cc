@@ -355,6 +355,40 @@ napi_value Zero(napi_env env, napi_callback_info info) {
     if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
     return undef(env);
 }
+// launch-bound sequences as HIP graphs (mirt.h): captureBegin(ctx), captureEnd(ctx) -> graph, graphLaunch(ctx, graph), graphRelease(graph)
+napi_value CaptureBegin(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* c;
+    if (!get_ext(env, argv[0], &c)) return throw_type(env, "captureBegin(ctx)");
+    int rc = mirt_capture_begin((mirt_ctx*)c);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    return undef(env);
+}
+napi_value CaptureEnd(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* c;
+    if (!get_ext(env, argv[0], &c)) return throw_type(env, "captureEnd(ctx)");
+    mirt_graph* g = nullptr;
+    int rc = mirt_capture_end((mirt_ctx*)c, &g);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    return mk_ext(env, g);
+}
+napi_value GraphLaunch(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    void *c, *g;
+    if (!get_ext(env, argv[0], &c) || !get_ext(env, argv[1], &g)) return throw_type(env, "graphLaunch(ctx, graph)");
+    int rc = mirt_graph_launch((mirt_ctx*)c, (mirt_graph*)g);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    return undef(env);
+}
+napi_value GraphRelease(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* g;
+    if (!get_ext(env, argv[0], &g)) return throw_type(env, "graphRelease(graph)");
+    int rc = mirt_graph_release((mirt_graph*)g);
+    if (rc) return throw_mirt(env, rc, nullptr);
+    return undef(env);
+}
 // gridBuild(ctx, kind, primsF64Buf, count, nSlabs, boundsFloat64Array(6)) -> {offsets, order, total}
 napi_value GridBuild(napi_env env, napi_callback_info info) {
     ARGS(6);
@@ -438,6 +472,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"kernelPreferredMultiple", KernelPreferredMultiple}, {"kernelSetArg", KernelSetArg}, {"enqueue", Enqueue},
         {"renderPass", RenderPass}, {"gridBuild", GridBuild}, {"gridGatherTriangles", GridGatherTriangles},
         {"gridGatherSpheres", GridGatherSpheres}, {"gridGatherU32", GridGatherU32}, {"seedFill", SeedFill}, {"zero", Zero}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
+        {"captureBegin", CaptureBegin}, {"captureEnd", CaptureEnd}, {"graphLaunch", GraphLaunch}, {"graphRelease", GraphRelease},
     };
     for (auto& f : fns) {
         napi_value fn;

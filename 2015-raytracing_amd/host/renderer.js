@@ -85,6 +85,7 @@ class GranularRenderer {
     opt = opt || {};
     this.p = packed;
     this.device = pickDevice(opt.device);
+    this.useGraph = !!opt.graph;
     this.ctx = webcl.createContext(this.device);           // createCLBasicResources (code.js:576-608)
     this.q = this.ctx.createCommandQueue();
     this.program = this.ctx.createProgram(MANIFEST);
@@ -187,17 +188,33 @@ class GranularRenderer {
         k.triangleShadowTrace.setArg(5, u32(s.nSlabs)); this._run(k.triangleShadowTrace);
       }
       k.sceneRender.setArg(4, light.scene); this._run(k.sceneRender);  // executeSceneRender (code.js:1402-1408)
-      this.q.finish();
+      if (!this._recording) this.q.finish();   // the reference finishes the queue here (code.js:1406); a recording cannot wait
     }
   }
-  executeRender(bounces) {  // code.js:1806-1854
+  _segments(bounces) {
     const k = this.k, p = this.p;
     k.initTrace.setArg(4, p.cam);
     this.q.enqueueNDRangeKernel(k.initTrace, 2, null, this.gws.initTrace, this.lws.initTrace);
     this._closest();
     for (const light of p.lights) { k.lightRender.setArg(3, light.light); this._run(k.lightRender); }
     this._direct();
-    for (let j = 0; j < (bounces === undefined ? 5 : bounces); j++) { this._run(k.bouncePaths); this._closest(); this._direct(); }
+    for (let j = 0; j < bounces; j++) { this._run(k.bouncePaths); this._closest(); this._direct(); }
+  }
+  // code.js:1806-1854.  opt.graph (constructor): from the second pass on the pass body -- 40-odd launches, each a few microseconds on
+  // the page's 320x240 canvas -- is one HIP graph replay; copyToPixel stays outside, its scale changes every pass (code.js:1412)
+  executeRender(bounces) {
+    const k = this.k, p = this.p;
+    bounces = bounces === undefined ? 5 : bounces;
+    if (this.useGraph && this.passes > 1) {
+      if (!this._graph || this._graphBounces !== bounces) {
+        if (this._graph) this._graph.release();
+        this.q.captureBegin();
+        this._recording = true;
+        try { this._segments(bounces); } finally { this._recording = false; this._graph = this.q.captureEnd(); }
+        this._graphBounces = bounces;
+      }
+      this.q.launchGraph(this._graph);
+    } else this._segments(bounces);
     k.copyToPixel.setArg(2, f32(1.0 / (p.rays_per_pixel * this.passes)));  // executeCopyToPixel (code.js:1410-1415)
     this.q.enqueueNDRangeKernel(k.copyToPixel, 1, null, this.gws.copyToPixel, [64]);
     this.passes++;

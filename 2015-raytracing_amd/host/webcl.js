@@ -151,6 +151,10 @@ class WebCLCommandQueue {
     wrap(() => native().enqueue(this.ctx.h, kernel.h, dim, Array.from(globalWS), localWS ? Array.from(localWS) : null));
   }
   finish() { wrap(() => native().finish(this.ctx.h)); }
+  // ---- extension: record a launch-bound sequence of enqueues once, replay it as a HIP graph (mirt_capture_begin/_end, mirt_graph_launch)
+  captureBegin() { wrap(() => native().captureBegin(this.ctx.h)); }
+  captureEnd() { return { h: wrap(() => native().captureEnd(this.ctx.h)), release() { native().graphRelease(this.h); } }; }
+  launchGraph(g) { wrap(() => native().graphLaunch(this.ctx.h, g.h)); }
   // ---- extension: one fused launch for the whole pass (mirt_render_pass) -------------------
   renderPass(desc) {
     const g = (s) => s && { prims: s.prims.h, normals: s.normals ? s.normals.h : undefined, matid: s.matid ? s.matid.h : undefined,

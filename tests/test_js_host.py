@@ -47,6 +47,25 @@ def test_pack_equals_reference_host(name):
     same_packed(json.loads(bytes(fx["scene_json"]).decode()), got)
 
 
+@pytest.mark.gpu
+def test_node_graph_replayed_passes(tmp_path):
+    """`render --granular --graph`: five kernel-by-kernel passes through Node, the pass body replayed as one HIP graph from the third
+    pass on (queue.captureBegin / captureEnd / launchGraph) == oracle."""
+    import a10_pass as A
+    fx, sc = load_fixture("own_gems_48x36_r4")
+    seeds = A.make_seeds(sc.total_rays, seed_base=77)
+    sfile = str(tmp_path / "seeds.i32")
+    seeds.tofile(sfile)
+    st = A.PassState(sc, seeds)
+    orc = A.load_oracle()
+    for p in range(5):
+        A.run_pass(orc, sc, st, init_acu=(p == 0))
+    out = str(tmp_path / "frame.rgba")
+    run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "gems.xml"), "48", "36", "4", "5", out, "--granular", "--graph", "--seeds", sfile)
+    assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), st.pixel)
+    assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(A.radiance_sums(st.acu, 4)))
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_PAGE), reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("scene", ["basic", "basic2", "cornell", "cornell_official", "cornell_teapot", "cornell_teapot2",
                                    "cornell_teapot3", "threeLights", "triangles", "twoLights"])
