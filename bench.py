@@ -49,7 +49,8 @@ TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 10.62e9, "write_bytes": 10.62e9, "sou
 
 
 def cpu_baseline(packed_json, log, bounces):
-    """The CPU oracle (our plain-C restatement, OpenMP over all host cores) on a bounded sample."""
+    """The CPU oracle (our plain-C restatement, OpenMP) on a bounded sample.  Threads = the CPUs this process may really use: the
+    affinity mask capped by the cgroup CPU quota (oracle/a10_pass.py cpu_budget); `cores` reports that number."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import a10_pass as A
     d = json.loads(packed_json)
@@ -66,7 +67,7 @@ def cpu_baseline(packed_json, log, bounces):
     A.run_pass(k, sc, st, bounces=bounces)
     dt = time.perf_counter() - t0
     log(f"cpu_baseline: {sc.total_rays} samples in {dt:.2f} s on {cores} threads")
-    return {"value": round(sc.total_rays / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+    return {"value": round(sc.total_rays / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "host_cpus_visible": os.cpu_count(), "kind": "port",
             "sample": f"cornell.xml {w}x{h} rpp{rpp} 1 pass {bounces} bounces ({sc.total_rays} samples, {dt:.1f} s wall)"}
 
 

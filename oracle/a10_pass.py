@@ -94,8 +94,31 @@ def load_ref():
     return CpuKernels(os.path.join(HERE, "_ref", "libref_a10.so"), "ref_a10_")
 
 
+def cpu_budget():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a 256-thread host can hand a container
+    sixteen CPUs' worth of time; 128 OpenMP threads inside that quota only fight each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                        # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(np.ceil(q / p))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def load_oracle():
-    return CpuKernels(os.path.join(HERE, "liboracle.so"), "oracle_a10_")
+    k = CpuKernels(os.path.join(HERE, "liboracle.so"), "oracle_a10_")
+    k.lib.oracle_set_threads.argtypes = [C.c_int]
+    k.lib.oracle_set_threads.restype = None
+    k.lib.oracle_set_threads(cpu_budget())
+    return k
 
 
 def _ceil(n, m):

@@ -18,7 +18,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _lib(kind, assign):
     if kind == "ref":
         return C.CDLL(os.path.join(HERE, "_ref", f"libref_a{assign:02d}.so")), f"ref_a{assign:02d}_"
-    return C.CDLL(os.path.join(HERE, "liboracle.so")), f"oracle_a{assign:02d}_"
+    lib = C.CDLL(os.path.join(HERE, "liboracle.so"))
+    lib.oracle_set_threads.argtypes = [C.c_int]
+    lib.oracle_set_threads.restype = None
+    lib.oracle_set_threads(A.cpu_budget())      # threads = the CPUs this process may really use (cgroup quota), see a10_pass.cpu_budget
+    return lib, f"oracle_a{assign:02d}_"
 
 
 def _p(a):
