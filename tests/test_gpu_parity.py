@@ -244,6 +244,49 @@ def test_degenerate_scenes_match_oracle(ctx, pkg, case):
     fr.release()
 
 
+MEDIUM = ["basic_32x24_r4", "cornell_32x24_r4", "triangles_32x24_r4", "twoLights_32x24_r4", "threeLights_32x24_r1", "cornell_official_64x48_r1",
+          "cornell_teapot3_32x24_r4", "own_flat_32x24_r4", "own_gems_48x36_r4", "own_studio_48x36_r4"]
+
+
+@pytest.mark.parametrize("name", MEDIUM)
+def test_medium_frames_match_oracle(ctx, pkg, name):
+    """Every scene the fixtures carry (the reference's A10 scenes and ours), re-sized to 240x135 at 16 rays per pixel and depth 8
+    (518 k samples, two progressive passes): the fused pass against the CPU oracle on the same seeds, every accumulator and seed."""
+    from raytracing_amd.pyhost import render
+    fx, sc0 = load_fixture(name)
+    sc = _variant(sc0, width=240, height=135, rays_per_pixel=16)
+    seeds = A.make_seeds(sc.total_rays, seed_base=5)
+    orc = A.load_oracle()
+    st = A.PassState(sc, seeds)
+    fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+    for p in range(2):
+        A.run_pass(orc, sc, st, bounces=8, init_acu=(p == 0))
+        fr.execute_render(bounces=8)
+    assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(st.acu))
+    assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
+    assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), st.pixel)
+    fr.release()
+
+
+def test_cornell_8M_samples_match_oracle(ctx, pkg):
+    """The headline scene at 960x540, 16 rays per pixel, depth 8 (8.3 M samples -- about one deferred sample per 1.7 M goes to the
+    exact kernel): fused pass == CPU oracle, every accumulator, seed and pixel."""
+    from raytracing_amd.pyhost import render
+    fx, sc0 = load_fixture("cornell_32x24_r4")
+    sc = _variant(sc0, width=960, height=540, rays_per_pixel=16)
+    seeds = A.make_seeds(sc.total_rays)
+    orc = A.load_oracle()
+    st = A.PassState(sc, seeds)
+    A.run_pass(orc, sc, st, bounces=8)
+    fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+    fr.execute_render(bounces=8)
+    assert ctx.pass_deferred() > 0
+    assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(st.acu))
+    assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
+    assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), st.pixel)
+    fr.release()
+
+
 def test_headline_frame_two_exact_routes_agree(ctx, pkg):
     """BASELINE config 4 at its full size and depth (1920x1080, 256 rays per pixel, 8 bounces = 531 M samples): the default pair
     (optimistic kernel with every hand-written exact form -- 3-operation quotients, refined reciprocals, 9-operation sqrt, min/max box
