@@ -185,7 +185,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 // FAST = false: the exact kernel (true divisions).  With `list` it recomputes the deferred samples; with list == nullptr it
 //               is the whole pass (geometry outside the guard, or PT_EXACT_FAST_DIV = 0).
 #ifndef PT_FUSED_WAVES_FAST
-#define PT_FUSED_WAVES_FAST 6   // the optimistic kernel: 80 VGPRs, 44 B scratch (A/B without SLP packing: 5 -> 168.9 ms, 6 -> 161.6, 7 -> 162.2, 8 -> 178.4; exact kernel 178.8)
+#define PT_FUSED_WAVES_FAST 7   // the optimistic kernel without the grid walk: 63 VGPRs, no scratch (same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
 #endif
 // GRIDS = false: every set is a single cell (n == 1: the reference's loose spheres and triangles, A10 code.js:399): only the
 //                wave-uniform loops are compiled in.  Without the DDA the register allocator needs 74 VGPRs and no scratch
