@@ -45,7 +45,11 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
     out[3u * i + 1] = make_float4(e1.x, e1.y, e1.z, n.y);
     out[3u * i + 2] = make_float4(e2.x, e2.y, e2.z, n.z);
     auto bad = [](float v) { const float a = __builtin_fabsf(v); return !(v == 0.0f || (a >= 9.094947e-13f && a <= 1.0995116e12f)); };
-    if (bad(n.x) || bad(n.y) || bad(n.z)) atomicOr(insane, 1u);
+    // ... and every vertex / edge component within 2^21 in magnitude (NaN fails): the bounds of the set are the caller's word, the
+    // finiteness arguments of the optimistic kernel (pt_trace.hpp) are about the triangles themselves
+    auto big = [](float v) { return !(__builtin_fabsf(v) <= 2097152.0f); };
+    if (bad(n.x) || bad(n.y) || bad(n.z) || big(p0.x) || big(p0.y) || big(p0.z) || big(e1.x) || big(e1.y) || big(e1.z) || big(e2.x) || big(e2.y) || big(e2.z))
+        atomicOr(insane, 1u);
 }
 
 // Cold per-ray state parked in LDS instead of registers: the accumulator (touched once per shading event) and the
