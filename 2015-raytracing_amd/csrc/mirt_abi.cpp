@@ -747,7 +747,7 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     return MIRT_OK;
 }
 
-int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
+static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_render_pass: unknown context");
     if (!d || d->struct_size != sizeof(mirt_pass_desc)) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: descriptor size mismatch");
     if (!d->width || !d->height || !d->rays_per_pixel) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: empty image");
@@ -779,6 +779,7 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
     A.width = d->width; A.height = d->height; A.rpp = d->rays_per_pixel;
     A.row0 = d->row0; A.nrows = nrows; A.bounces = d->bounces;
     A.n_lights = d->n_lights;
+    A.fresh = fresh ? 1u : 0u;
     int rc;
     if (d->spheres && (rc = fill_grid(ctx, "spheres", d->spheres, false, true, &A.sets[A.n_sets++]))) return rc;
     if (d->triangles && (rc = fill_grid(ctx, "triangles", d->triangles, true, true, &A.sets[A.n_sets++]))) return rc;
@@ -841,6 +842,9 @@ int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) {
     d->acu->version++;
     return MIRT_OK;
 }
+
+int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) { return render_pass_impl(ctx, d, false); }
+int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* d) { return render_pass_impl(ctx, d, true); }
 
 int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_exact_only: unknown context");

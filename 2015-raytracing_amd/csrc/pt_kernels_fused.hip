@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     bound.hi = mk3(A.bound[4], A.bound[5], A.bound[6]);
 
     int32_t seed = A.seeds[lid];
-    float4 acc = ((const float4*)A.acu)[lid];
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // initAcu (A10 code.cl:448-456) when the pass is a frame's first
+    if (!A.fresh) acc = ((const float4*)A.acu)[lid];
     Park park;
 #if PT_PARK_LDS
     __shared__ float park_mem[PT_PARK_WORDS][256];

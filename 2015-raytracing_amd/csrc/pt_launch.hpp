@@ -71,6 +71,7 @@ struct FusedArgs {
     int32_t* seeds;          // [nrows*width*rpp], read-modify-write
     void* acu;               // float4[nrows*width*rpp], accumulated into
     const void* uv;          // rpp == 1: float2[nrows*width] lens draws from launch_lensDraws
+    uint32_t fresh;          // 1: the accumulator starts at zero and is not read (initAcu folded into the pass, mirt_render_first_pass)
 };
 // fast: the optimistic kernel (writes deferred samples' bits into defer_mask); !fast: the exact kernel over `list` (or everything)
 void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words);

@@ -77,6 +77,7 @@ SYMBOLS = {
     "mirt_kernel_preferred_multiple": (C.c_int, [C.c_void_p]),
     "mirt_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "mirt_render_pass": (C.c_int, [C.c_void_p, C.POINTER(_PassDesc)]),
+    "mirt_render_first_pass": (C.c_int, [C.c_void_p, C.POINTER(_PassDesc)]),
     "mirt_pass_deferred": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mirt_ctx_set_exact_only": (C.c_int, [C.c_void_p, C.c_int]),
     "mirt_seed_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]),
@@ -342,8 +343,10 @@ class Context:
         out.release()
         return r
 
-    def render_pass(self, desc):
-        self._chk(lib().mirt_render_pass(self.h, C.byref(desc)))
+    def render_pass(self, desc, fresh=False):
+        """fresh: the frame's first pass with initAcu folded in (mirt_render_first_pass): acu is not read."""
+        f = lib().mirt_render_first_pass if fresh else lib().mirt_render_pass
+        self._chk(f(self.h, C.byref(desc)))
 
     def destroy(self):
         if self.h:

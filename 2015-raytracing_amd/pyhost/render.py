@@ -218,10 +218,11 @@ class FusedRenderer:
         self.passes = 1
         self._desc = None
 
-    def execute_render(self, bounces=5):
+    def execute_render(self, bounces=5, fresh=False):
+        """fresh: first pass of a frame, accumulator initialised by the pass itself (no ctx.zero needed)."""
         d = self.dev.pass_desc(self.seeds, self.acu, self.pixel, self.radiance, pass_index=self.passes, bounces=bounces,
                                row0=self.row0, nrows=self.nrows)
-        self.ctx.render_pass(d)
+        self.ctx.render_pass(d, fresh=fresh)
         self.passes += 1
 
     def release(self):

@@ -35,17 +35,17 @@ import __graft_entry__ as graft  # noqa: E402
 
 # measured constants (DESIGN.md "Algorithmic work"): oracle/liboracle_count.so on cornell.xml 320x240 rpp 16
 FLOPS_PER_SAMPLE = {5: 6632.7, 8: 9812.3}
-BYTES_PER_SAMPLE_FUSED = 40.0       # seed 4 in + 4 out, accumulator 16 in + 16 out
+BYTES_PER_SAMPLE_FUSED = 24.0       # seed 4 in + 4 out, accumulator 16 out (a frame's first pass does not read it)
 BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0
 PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA-counted)
 PEAK_HBM_GBS = 8000.0
-# VALU wave-instructions per sample-lane (SQ_INSTS_VALU / SQ_WAVES, profiles/r1l_final) and the issue rate one SIMD sustains on
+# VALU wave-instructions per sample-lane (SQ_INSTS_VALU / SQ_WAVES, profiles/r1m_final) and the issue rate one SIMD sustains on
 # plain fp32 VOP2 streams at 8 waves (profiles/micro/valu_rate.hip: 2.4 nominal cycles per wave-instruction; the 2-cycle figure is the spec)
 VALU_INSTR_PER_SAMPLE = {8: 25170.0}
 SIMDS, NOMINAL_HZ, MEASURED_ISSUE_CYCLES = 1024, 2.4e9, 2.4
 # HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r1d_park_lds: FETCH_SIZE x 2 + WRITE_SIZE,
 # KiB -> bytes; gfx950 halves FETCH_SIZE on wide coalesced reads, MI355X_MICROARCH.md).  Valid for the default workload only.
-TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 10.62e9, "write_bytes": 10.62e9, "source": "profiles/r1l_final/pmc_summary.json"}
+TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 2.12e9, "write_bytes": 10.62e9, "source": "profiles/r1m_final/pmc_summary.json"}
 
 
 def cpu_baseline(packed_json, log, bounces):
@@ -139,11 +139,11 @@ def main():
     frame = torch.empty(world * tile.numel(), dtype=torch.uint8, device="cuda") if use_dist else None
 
     def step():
-        # a step re-renders the same frame: restore the accumulator and the seeds it started from
-        ctx.zero(fr.acu)
+        # a step re-renders the same frame: restore the seeds it started from; the accumulator is initialised by the pass itself
+        # (mirt_render_first_pass = preRender's initAcu folded into the first pass, A10 code.js:1078-1099)
         ctx.seed_fill(fr.seeds, fr.first_ray, fr.nrays, 0)
         fr.passes = 1
-        fr.execute_render(bounces=args.bounces)
+        fr.execute_render(bounces=args.bounces, fresh=True)
         if use_dist:
             tiling.gather_tiles(tile, frame)
 
@@ -197,10 +197,10 @@ def main():
             "achieved_Ginstr_s": round(VALU_INSTR_PER_SAMPLE[args.bounces] * local_samples / 64.0 / (fused_ms * 1e-3) / 1e9, 1),
             "attainable_Ginstr_s": round(SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES / 1e9, 1), "spec_Ginstr_s": round(SIMDS * NOMINAL_HZ / 2.0 / 1e9, 1),
             "frac_of_attainable": round(VALU_INSTR_PER_SAMPLE[args.bounces] * local_samples / 64.0 / (fused_ms * 1e-3) / (SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES), 4),
-            "source": "profiles/r1l_final/pmc_summary.json, profiles/micro/README.md"},
+            "source": "profiles/r1m_final/pmc_summary.json, profiles/micro/README.md"},
         "roofline_hbm": {"kernel": "pt::k_fusedPass<true,false>", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
-                         "traffic_note": "algorithmic 21.2 GB/launch; measured 21.2 GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes): no re-reads, no scratch",
+                         "traffic_note": "algorithmic 12.7 GB/launch (seeds in + out, accumulator out); measured 2.12 + 10.62 GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes): no re-reads, no scratch",
                          "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -209,10 +209,9 @@ def main():
         # the reference's own depth (five bounces), same frame, two untimed-warmup-free steps: reported beside the headline
         t5 = []
         for _ in range(2):
-            ctx.zero(fr.acu)
             ctx.seed_fill(fr.seeds, fr.first_ray, fr.nrays, 0)
             fr.passes = 1
-            fr.execute_render(bounces=5)
+            fr.execute_render(bounces=5, fresh=True)
             t5.append(ctx.pass_timing()[0])
         out["depth5"] = {"launch_ms": round(float(np.mean(t5)), 3), "Msamples_per_s_kernel": round(fr.nrays / np.mean(t5) / 1e3, 1),
                          "flops_per_sample": FLOPS_PER_SAMPLE[5], "frac": round(FLOPS_PER_SAMPLE[5] * fr.nrays / (np.mean(t5) * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4)}

@@ -164,6 +164,10 @@ typedef struct mirt_pass_desc {
 
 /* rays_per_pixel must be k*k, as the reference host makes it (A10 code.js:540): MIRT_E_ARG otherwise */
 MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
+/* The first pass of a frame with preRender's initAcu (A10 code.js:1078-1099, code.cl:448-456) folded in: `acu` is not read, every
+ * accumulator starts at (0,0,0,0).  Saves the zeroing launch and half of the pass's memory traffic; results equal
+ * mirt_zero(acu) + mirt_render_pass. */
+MIRT_API int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
 /* Two ways to run the pass, identical results.  Default: the optimistic pair -- a kernel whose divisions are 3-operation
  * forms proven bit-exact inside a guard window (exhaustively, on the device: profiles/r1_divcheck_exhaustive.txt), plus the
  * exact kernel re-running the samples whose rays left the window (NaN rays, axis-parallel directions, ...); it needs every

@@ -272,6 +272,21 @@ def test_medium_frames_match_oracle(ctx, pkg, name):
     fr.release()
 
 
+@pytest.mark.parametrize("name", ["cornell_16x12_r9", "cornell_teapot3_32x24_r4"])
+def test_first_pass_initialises_the_accumulator(ctx, pkg, name):
+    """mirt_render_first_pass = initAcu folded into the pass: over an accumulator full of junk it gives what zeroing + a normal pass
+    gives (the r9 case defers a ninth of its samples to the exact kernel, which must start them from zero as well)."""
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture(name)
+    fr = render.FusedRenderer(ctx, sc, seeds=fx["seeds_in"])
+    fr.acu.write(np.random.default_rng(1).normal(size=sc.total_rays * 4).astype(np.float32))
+    fr.execute_render(fresh=True)
+    assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(fx["f_acu"]))
+    assert np.array_equal(fr.seeds.read(np.int32), fx["f_seeds"])
+    assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), fx["pixel"])
+    fr.release()
+
+
 def test_cornell_8M_samples_match_oracle(ctx, pkg):
     """The headline scene at 960x540, 16 rays per pixel, depth 8 (8.3 M samples -- about one deferred sample per 1.7 M goes to the
     exact kernel): fused pass == CPU oracle, every accumulator, seed and pixel."""
