@@ -333,7 +333,9 @@ napi_value RenderPass(napi_env env, napi_callback_info info) {
     p.acu = prop_buf(env, d, "acu");
     p.pixel = prop_buf(env, d, "pixel");
     p.radiance = prop_buf(env, d, "radiance");
-    int rc = mirt_render_pass((mirt_ctx*)c, &p);
+    bool first = false;   // desc.firstPass: initAcu folded into the pass (mirt_render_first_pass)
+    { napi_value v; bool has = false; if (napi_has_named_property(env, d, "firstPass", &has) == napi_ok && has && napi_get_named_property(env, d, "firstPass", &v) == napi_ok) napi_get_value_bool(env, v, &first); }
+    int rc = first ? mirt_render_first_pass((mirt_ctx*)c, &p) : mirt_render_pass((mirt_ctx*)c, &p);
     if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
     return undef(env);
 }

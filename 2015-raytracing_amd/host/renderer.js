@@ -250,8 +250,7 @@ class FusedRenderer {
     this.seeds = this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 4);
     if (opt.seeds) this.q.enqueueWriteBuffer(this.seeds, false, 0, this.nrays * 4, opt.seeds.subarray(first, first + this.nrays), []);
     else this.q.seedFill(this.seeds, first, this.nrays, opt.seedBase || 0);
-    this.acu = this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 16);
-    this.q.zero(this.acu);
+    this.acu = this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 16);   // not zeroed: the first pass initialises it (firstPass below)
     this.pixel = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, this.npix * 4);
     this.radiance = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, this.npix * 16);
     this.passes = 1;
@@ -261,7 +260,8 @@ class FusedRenderer {
     this.q.renderPass({ width: p.width, height: p.height, raysPerPixel: p.rays_per_pixel, row0: this.row0, nrows: this.nrows,
       bounces: bounces === undefined ? 5 : bounces, passIndex: this.passes, cam: p.cam, sceneBounds: p.bounds,
       focalLength: p.focal_length, lensRad: p.lens_rad, spheres: d.sph, triangles: d.tri, meshes: d.meshes, lights: p.lights,
-      material: d.material, seeds: this.seeds, acu: this.acu, pixel: this.pixel, radiance: this.radiance });
+      material: d.material, seeds: this.seeds, acu: this.acu, pixel: this.pixel, radiance: this.radiance,
+      firstPass: this.passes === 1 });   // preRender's initAcu (code.js:1078-1099) folded into the frame's first pass
     this.passes++;
   }
   readPixels() { const o = new Uint8ClampedArray(this.npix * 4); this.q.enqueueReadBuffer(this.pixel, false, 0, o.length, o, []); this.q.finish(); return o; }
