@@ -40,12 +40,18 @@ function makeSandbox(pageDir, opts) {
   }
   const sandbox = {
     console: { log() {} }, alert: (m) => { throw new Error("alert: " + m); }, setTimeout() {}, XMLHttpRequest: XHR,
-    webcl: webcl, WebCL: WebCL,
+    webcl: opts.webcl || webcl, WebCL: opts.WebCL || WebCL,
     document: { getElementById: (id) => elems[id] || (elems[id] = { value: "", selectedIndex: 0, innerHTML: "", add() {}, options: [] }),
                 createElement: () => ({}) },
   };
   sandbox.window = sandbox;
   vm.createContext(sandbox);
+  // prepareInitSeeds draws its seeds from Math.random() (A10 code.js:1140-1146); a reproducible run pins the generator (mulberry32)
+  if (opts.randomSeed !== undefined) {
+    vm.runInContext(`(function () { var a = ${opts.randomSeed >>> 0};
+      Math.random = function () { a = (a + 0x6D2B79F5) | 0; var t = Math.imul(a ^ (a >>> 15), 1 | a);
+        t = (t + Math.imul(t ^ (t >>> 7), 61 | t)) ^ t; return ((t ^ (t >>> 14)) >>> 0) / 4294967296; }; })();`, sandbox);
+  }
   for (const f of ["lib/gl-matrix.js", "lib/utilities.js", "tri/meshDataVersion1.js", "mol/pdbParserV1.js", "code.js"]) {
     const p = path.join(pageDir, f);
     if (fs.existsSync(p)) vm.runInContext(fs.readFileSync(p, "utf8"), sandbox, { filename: f });
@@ -53,8 +59,8 @@ function makeSandbox(pageDir, opts) {
   return sandbox;
 }
 
-function run(pageDir, sceneName, width, height, sqrtRpp, passes) {
-  const sb = makeSandbox(pageDir, { width: width, height: height });
+function run(pageDir, sceneName, width, height, sqrtRpp, passes, opts) {
+  const sb = makeSandbox(pageDir, Object.assign({ width: width, height: height }, opts || {}));
   const js = (s) => vm.runInContext(s, sb);
   // what main() + the page's controls would have set up (A10 code.js:422-460, 530-571)
   js(`findWebCLDevices(); width=${width}; height=${height};

@@ -6,8 +6,10 @@
 // same enqueue order, same NDRange padding.  FusedRenderer asks the runtime for the same pass
 // in one launch (queue.renderPass).  Both produce bit-identical frames.
 "use strict";
-const { webcl } = require("./webcl.js");
+let { webcl } = require("./webcl.js");
 const scene = require("./scene.js");
+// tests point the drivers at another implementation of the same object model (./webcl_record.js) to compare call streams
+function setWebCL(impl) { webcl = impl; }
 
 const KERNELS = ["sizeofRay", "sizeofPoi", "initAcu", "initTrace", "sphereTrace", "triangleTrace", "meshTrace", "lightRender",
                  "initShadowTrace", "sphereShadowTrace", "triangleShadowTrace", "sceneRender", "bouncePaths", "copyToPixel"];
@@ -139,8 +141,8 @@ class GranularRenderer {
       k.meshTrace = prog.createKernel("meshTrace");
       [u32(n), b.pois, b.rays].forEach((v, i) => k.meshTrace.setArg(i, v));
     }
-    // prepareInitShadowTrace
-    b.shadow = ctx.createBuffer(webcl.MEM_READ_WRITE, n * raySize);
+    // prepareInitShadowTrace: asks for the Ray size again (code.js:1417-1419)
+    b.shadow = ctx.createBuffer(webcl.MEM_READ_WRITE, n * this._structSize("Ray"));
     k.initShadowTrace = prog.createKernel("initShadowTrace");
     k.initShadowTrace.setArg(0, b.shadow); k.initShadowTrace.setArg(1, b.pois); k.initShadowTrace.setArg(2, u32(n)); k.initShadowTrace.setArg(4, b.seeds);
     if (d.sph) {
@@ -299,4 +301,4 @@ function renderFile(file, width, height, rpp, passes, opt) {
   return res;
 }
 
-module.exports = { GranularRenderer, FusedRenderer, renderFile, radianceSums, getLocalWS, KERNELS };
+module.exports = { GranularRenderer, FusedRenderer, renderFile, radianceSums, getLocalWS, KERNELS, setWebCL };
