@@ -9,6 +9,7 @@
 #include "pt_launch.hpp"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cctype>
@@ -18,6 +19,8 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <atomic>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -27,14 +30,26 @@ constexpr size_t kRayBytes = 48, kPoiBytes = 64, kAcuBytes = 16;
 
 thread_local std::string t_last_error = "";
 
+// Live handles, by address AND kind: a handle of the wrong type (a kernel passed where a buffer is expected, a stale address that
+// `new` has since handed to another kind of object) fails validation instead of being dereferenced as something it is not.
+enum HandleKind : uint8_t { H_CTX = 1, H_BUF, H_KERNEL, H_GRAPH, H_GROUP };
 std::mutex g_live_mu;
-std::unordered_set<const void*> g_live;
+std::unordered_map<const void*, HandleKind> g_live;
+std::atomic<uint64_t> g_next_uid{1};
 
-void live_add(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.insert(p); }
+void live_add(const void* p, HandleKind k) { std::lock_guard<std::mutex> l(g_live_mu); g_live[p] = k; }
 void live_del(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.erase(p); }
-bool live_has(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); return p && g_live.count(p) != 0; }
+bool live_is(const void* p, HandleKind k) {
+    if (!p) return false;
+    std::lock_guard<std::mutex> l(g_live_mu);
+    auto it = g_live.find(p);
+    return it != g_live.end() && it->second == k;
+}
 
 }  // namespace
+
+struct mirt_graph;
+struct mirt_group;
 
 struct mirt_ctx {
     int device = -1;
@@ -52,12 +67,26 @@ struct mirt_ctx {
     hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
     bool pe_valid = false;
     bool capturing = false;       // between mirt_capture_begin and mirt_capture_end: the stream records, nothing may wait on it
+    // objects created on this context; mirt_ctx_destroy reaps what the host did not release (the reference host leaks its
+    // bouncePaths kernel: A10 code.js:1444-1455 never pushes it on cl_resources)
+    std::unordered_set<mirt_buf*> bufs;
+    std::unordered_set<mirt_kernel*> kernels;
+    std::unordered_set<mirt_graph*> graphs;
+    mirt_group* group = nullptr;  // set when the context belongs to a device group (mirt_group_create)
+    // what a recording has touched so far (mirt_graph pins): device allocations a replay will read or write
+    uint64_t scratch_gen = 1, defer_gen = 1;   // bumped whenever the allocation is replaced
+    struct Pin { mirt_buf* buf; uint64_t uid; uint64_t prep_gen; uint64_t version; bool content; };
+    std::vector<Pin> cap_pins;
+    bool cap_scratch = false, cap_defer = false;
 };
 
 struct mirt_graph {
     mirt_ctx* ctx = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // every allocation the recording captured a raw pointer of; mirt_graph_launch refuses to replay once one of them is gone
+    std::vector<mirt_ctx::Pin> pins;
+    uint64_t scratch_gen = 0, defer_gen = 0;   // 0: not used by the recording
 };
 
 struct mirt_buf {
@@ -66,7 +95,8 @@ struct mirt_buf {
     size_t bytes = 0;
     bool owned = true;
     unsigned flags = 0;
-    uint64_t version = 1;  // bumped by every host write / device zero
+    uint64_t uid = 0;      // unique per allocation: tells a live handle from a new object at a recycled address
+    uint64_t version = 1;  // bumped by every host write / device zero / mirt_buf_invalidate
     // cell-offset validation cache
     uint64_t off_version = 0;
     uint32_t off_n = 0;
@@ -75,6 +105,7 @@ struct mirt_buf {
     void* prep = nullptr;
     size_t prep_bytes = 0;
     uint64_t prep_version = 0;
+    uint64_t prep_gen = 1;    // bumped whenever `prep` is freed or replaced
     bool prep_sane = false;   // every plane-normal component is 0 or in [2^-40, 2^40]
 };
 
@@ -133,6 +164,11 @@ struct mirt_kernel {
 
 namespace {
 
+bool live_has(const mirt_ctx* p) { return live_is(p, H_CTX); }
+bool live_has(const mirt_buf* p) { return live_is(p, H_BUF); }
+bool live_has(const mirt_kernel* p) { return live_is(p, H_KERNEL); }
+bool live_has(const mirt_graph* p) { return live_is(p, H_GRAPH); }
+
 int fail(mirt_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -170,11 +206,22 @@ uint32_t f2u_host(float f) {
 #define NOT_WHILE_CAPTURING(ctx, what) \
     do { if ((ctx)->capturing) return fail((ctx), MIRT_E_ARG, "%s is not possible inside mirt_capture_begin/end: run the sequence once before recording it", (what)); } while (0)
 
+// A recording captures raw device pointers.  Every buffer a recorded launch touches is pinned: (handle, allocation uid), plus --
+// `content` -- the version of its contents and the generation of its prepared copy when the launch relies on host-side
+// validation or preparation of those contents (cell-offset tables, triangle positions).
+void pin(mirt_ctx* ctx, const mirt_buf* b, bool content) {
+    if (!ctx->capturing) return;
+    for (auto& p : ctx->cap_pins)
+        if (p.buf == b) { p.content = p.content || content; return; }
+    ctx->cap_pins.push_back({const_cast<mirt_buf*>(b), b->uid, b->prep_gen, b->version, content});
+}
+
 int need(mirt_ctx* ctx, const char* what, const mirt_buf* b, uint64_t bytes) {
     if (!live_has(b)) return fail(ctx, MIRT_E_HANDLE, "%s: released or unknown buffer", what);
     if (b->ctx != ctx) return fail(ctx, MIRT_E_ARG, "%s: buffer belongs to another context", what);
     if ((uint64_t)b->bytes < bytes)
         return fail(ctx, MIRT_E_RANGE, "%s: buffer holds %zu bytes, launch needs %llu", what, b->bytes, (unsigned long long)bytes);
+    pin(ctx, b, false);
     return MIRT_OK;
 }
 
@@ -186,7 +233,8 @@ int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const
     const uint64_t cells = (uint64_t)n * n * n;
     int rc = need(ctx, what, off, (cells + 1) * 4);
     if (rc) return rc;
-    if (!(off->off_version == off->version && off->off_n == n)) {
+    // memory the caller owns (mirt_buf_wrap) can change behind the runtime's back: its verdict is never cached
+    if (!off->owned || !(off->off_version == off->version && off->off_n == n)) {
         NOT_WHILE_CAPTURING(ctx, "validating a new cell-offset table");
         std::vector<uint32_t> h(cells + 1);
         HIPCHK(ctx, hipMemcpyAsync(h.data(), off->ptr, (cells + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -197,6 +245,7 @@ int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const
         off->off_n = n;
         off->off_last = h[cells];
     }
+    pin(ctx, off, true);
     const uint64_t count = off->off_last;
     rc = need(ctx, what, prims, count * prim_stride);
     if (rc) return rc;
@@ -224,10 +273,10 @@ uint32_t exit_is_far_face(const float* b8, uint32_t n) {
 // (re)builds the prepared-triangle copy of a position buffer when its contents changed
 int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
     const size_t bytes = (size_t)count * 48;
-    if (pb->prep_version == pb->version && pb->prep_bytes >= bytes && (pb->prep || !bytes)) return MIRT_OK;
+    if (pb->owned && pb->prep_version == pb->version && pb->prep_bytes >= bytes && (pb->prep || !bytes)) { pin(ctx, pb, true); return MIRT_OK; }
     NOT_WHILE_CAPTURING(ctx, "preparing a new triangle buffer");
-    if (pb->prep) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pb->prep)); pb->prep = nullptr; pb->prep_bytes = 0; }
-    if (bytes) { HIPCHK(ctx, hipMalloc(&pb->prep, bytes)); pb->prep_bytes = bytes; }
+    if (pb->prep && pb->prep_bytes < bytes) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pb->prep)); pb->prep = nullptr; pb->prep_bytes = 0; pb->prep_gen++; }
+    if (bytes && !pb->prep) { HIPCHK(ctx, hipMalloc(&pb->prep, bytes)); pb->prep_bytes = bytes; pb->prep_gen++; }
     int rc = ensure_scratch(ctx, 16);
     if (rc) return rc;
     uint32_t insane = 0;
@@ -241,36 +290,76 @@ int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
 }
 
 int ensure_scratch(mirt_ctx* ctx, size_t bytes) {
+    if (ctx->capturing) ctx->cap_scratch = true;
     if (ctx->scratch_bytes >= bytes) return MIRT_OK;
     NOT_WHILE_CAPTURING(ctx, "growing the scratch buffer");
     if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    ctx->scratch_gen++;
     HIPCHK(ctx, hipMalloc(&ctx->scratch, bytes));
     ctx->scratch_bytes = bytes;
     return MIRT_OK;
 }
 
+// release paths shared by the public entry points and by mirt_ctx_destroy's reaping of leftovers
+void free_buf(mirt_buf* buf, bool ctx_alive) {
+    mirt_ctx* ctx = buf->ctx;
+    live_del(buf);
+    if (ctx_alive) {
+        ctx->bufs.erase(buf);
+        if ((buf->owned && buf->ptr) || buf->prep) {
+            (void)hipSetDevice(ctx->device);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        if (buf->owned && buf->ptr) (void)hipFree(buf->ptr);
+        if (buf->prep) (void)hipFree(buf->prep);
+    }
+    delete buf;
+}
+void free_kernel(mirt_kernel* k, bool ctx_alive) {
+    live_del(k);
+    if (ctx_alive) k->ctx->kernels.erase(k);
+    delete k;
+}
+void free_graph(mirt_graph* g, bool ctx_alive) {
+    live_del(g);
+    if (ctx_alive) { g->ctx->graphs.erase(g); (void)hipStreamSynchronize(g->ctx->stream); }
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
 }  // namespace
+
+// No C++ exception crosses the C boundary (include/mirt.h): every entry point is a function-try-block.
+namespace {
+int caught(const char* fn, const char* what) noexcept {
+    try { return fail(nullptr, MIRT_E_DEVICE, "%s: %s", fn, what); } catch (...) { return MIRT_E_DEVICE; }
+}
+}  // namespace
+#define MIRT_CATCH(fn, ret)                                                         \
+    catch (const std::bad_alloc&) { (void)caught(fn, "out of host memory"); ret; }  \
+    catch (const std::exception& e) { (void)caught(fn, e.what()); ret; }            \
+    catch (...) { (void)caught(fn, "unexpected C++ exception"); ret; }
 
 extern "C" {
 
-const char* mirt_version(void) { return "mirt 0.1 (gfx950)"; }
+const char* mirt_version(void) try { return "mirt 0.1 (gfx950)"; } MIRT_CATCH("mirt_version", return "")
 
-int mirt_device_count(void) {
+int mirt_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
-}
+} MIRT_CATCH("mirt_device_count", return MIRT_E_DEVICE)
 
-int mirt_device_name(int device, char* out, size_t cap) {
+int mirt_device_name(int device, char* out, size_t cap) try {
     if (!out || cap == 0) return fail(nullptr, MIRT_E_ARG, "mirt_device_name: null output");
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, MIRT_E_NODEVICE, "no HIP device %d", device); }
     snprintf(out, cap, "%s (%s, %d CUs)", p.name[0] ? p.name : "AMD Instinct (name not reported)", p.gcnArchName, p.multiProcessorCount);
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_device_name", return MIRT_E_DEVICE)
 
-int mirt_ctx_create(int device, mirt_ctx** out) {
-    if (!out) return fail(nullptr, MIRT_E_ARG, "mirt_ctx_create: null out");
+static int create_ctx(int device, mirt_ctx** out) {
     *out = nullptr;
     int n = mirt_device_count();
     if (n <= 0) return fail(nullptr, MIRT_E_NODEVICE, "no HIP device visible: libmirt needs an MI355X (gfx950); there is no CPU fallback");
@@ -287,15 +376,19 @@ int mirt_ctx_create(int device, mirt_ctx** out) {
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
     for (auto& e : c->pe) (void)hipEventCreate(&e);
-    live_add(c);
+    live_add(c, H_CTX);
     *out = c;
     return MIRT_OK;
 }
 
-int mirt_ctx_destroy(mirt_ctx* ctx) {
-    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_destroy: unknown context");
+static int destroy_ctx(mirt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
+    if (ctx->capturing) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(ctx->stream, &g); if (g) (void)hipGraphDestroy(g); ctx->capturing = false; }
     (void)hipStreamSynchronize(ctx->stream);
+    // whatever the host never released goes with the context; those handles become MIRT_E_HANDLE
+    while (!ctx->graphs.empty()) free_graph(*ctx->graphs.begin(), true);
+    while (!ctx->kernels.empty()) free_kernel(*ctx->kernels.begin(), true);
+    while (!ctx->bufs.empty()) free_buf(*ctx->bufs.begin(), true);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->defer) (void)hipFree(ctx->defer);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -307,28 +400,192 @@ int mirt_ctx_destroy(mirt_ctx* ctx) {
     return MIRT_OK;
 }
 
-const char* mirt_last_error(mirt_ctx* ctx) {
-    if (ctx && live_has(ctx)) return ctx->last_error.c_str();
-    return t_last_error.c_str();
+int mirt_ctx_create(int device, mirt_ctx** out) try {
+    if (!out) return fail(nullptr, MIRT_E_ARG, "mirt_ctx_create: null out");
+    return create_ctx(device, out);
+} MIRT_CATCH("mirt_ctx_create", return MIRT_E_DEVICE)
+
+int mirt_ctx_destroy(mirt_ctx* ctx) try {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_destroy: unknown context");
+    if (ctx->group) return fail(ctx, MIRT_E_ARG, "mirt_ctx_destroy: the context belongs to a device group; destroy the group");
+    return destroy_ctx(ctx);
+} MIRT_CATCH("mirt_ctx_destroy", return MIRT_E_DEVICE)
+
+// ---- device groups: N contexts in one process + the one exchange of the path ---------------------------------------------
+// RCCL is bound at run time (dlopen of librccl.so) the first time a group with more than one device -- or a forced RCCL gather --
+// is created: a single-GPU host never loads it.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+Rccl& rccl() {
+    static Rccl r;
+    if (r.lib || !r.err.empty()) return r;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!r.lib) { r.err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return r; }
+    auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("librccl.so lacks ") + n; return p; };
+    r.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
+    r.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    r.GroupStart = (int (*)())sym("ncclGroupStart");
+    r.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+    r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+    r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    return r;
+}
+constexpr int kNcclUint8 = 1;   // ncclUint8 / ncclChar family: rccl.h ncclDataType_t { ncclInt8 = 0, ncclUint8 = 1, ... }
+}  // namespace
+
+struct mirt_group {
+    std::vector<mirt_ctx*> ctxs;
+    std::vector<void*> comms;    // ncclComm_t per device; empty until a gather needs RCCL
+};
+
+static bool live_group(const mirt_group* g) { return live_is(g, H_GROUP); }
+
+static int group_comms(mirt_group* g) {
+    if (!g->comms.empty()) return MIRT_OK;
+    Rccl& R = rccl();
+    if (!R.err.empty()) return fail(g->ctxs[0], MIRT_E_DEVICE, "mirt_gather: %s", R.err.c_str());
+    std::vector<int> devs;
+    for (auto* c : g->ctxs) devs.push_back(c->device);
+    g->comms.assign(devs.size(), nullptr);
+    int rc = R.CommInitAll(g->comms.data(), (int)devs.size(), devs.data());
+    if (rc != 0) { g->comms.clear(); return fail(g->ctxs[0], MIRT_E_DEVICE, "ncclCommInitAll over %zu devices: %s", devs.size(), R.GetErrorString(rc)); }
+    return MIRT_OK;
 }
 
-int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream) {
+int mirt_group_create(const int* device_ids, int n, mirt_group** out) try {
+    if (!out) return fail(nullptr, MIRT_E_ARG, "mirt_group_create: null out");
+    *out = nullptr;
+    if (!device_ids || n < 1 || n > 64) return fail(nullptr, MIRT_E_ARG, "mirt_group_create: need 1..64 device ids");
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (device_ids[i] == device_ids[j]) return fail(nullptr, MIRT_E_ARG, "mirt_group_create: device %d listed twice", device_ids[i]);
+    mirt_group* g = new mirt_group();
+    for (int i = 0; i < n; ++i) {
+        mirt_ctx* c = nullptr;
+        int rc = create_ctx(device_ids[i], &c);
+        if (rc) { for (auto* d : g->ctxs) { d->group = nullptr; destroy_ctx(d); } delete g; return rc; }
+        c->group = g;
+        g->ctxs.push_back(c);
+    }
+    live_add(g, H_GROUP);
+    *out = g;
+    return MIRT_OK;
+} MIRT_CATCH("mirt_group_create", return MIRT_E_DEVICE)
+
+int mirt_group_size(const mirt_group* g) try { return live_group(g) ? (int)g->ctxs.size() : MIRT_E_HANDLE; } MIRT_CATCH("mirt_group_size", return MIRT_E_DEVICE)
+
+mirt_ctx* mirt_group_ctx(const mirt_group* g, int index) try {
+    if (!live_group(g) || index < 0 || index >= (int)g->ctxs.size()) { fail(nullptr, MIRT_E_ARG, "mirt_group_ctx: unknown group or index out of range"); return nullptr; }
+    return g->ctxs[index];
+} MIRT_CATCH("mirt_group_ctx", return nullptr)
+
+int mirt_group_destroy(mirt_group* g) try {
+    if (!live_group(g)) return fail(nullptr, MIRT_E_HANDLE, "mirt_group_destroy: unknown group");
+    for (auto* c : g->ctxs) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+    if (!g->comms.empty()) for (void* c : g->comms) if (c) (void)rccl().CommDestroy(c);
+    for (size_t i = 0; i < g->ctxs.size(); ++i) {
+        g->ctxs[i]->group = nullptr;
+        destroy_ctx(g->ctxs[i]);
+    }
+    live_del(g);
+    delete g;
+    return MIRT_OK;
+} MIRT_CATCH("mirt_group_destroy", return MIRT_E_DEVICE)
+
+void mirt_tile_rows(uint32_t height, uint32_t n_tiles, uint32_t index, uint32_t* row0, uint32_t* nrows) try {
+    // contiguous row tiles whose sizes differ by at most one row: the first height % n tiles take the extra row
+    if (!n_tiles || index >= n_tiles) { if (row0) *row0 = 0; if (nrows) *nrows = 0; return; }
+    const uint32_t q = height / n_tiles, r = height % n_tiles;
+    if (row0) *row0 = index * q + (index < r ? index : r);
+    if (nrows) *nrows = q + (index < r ? 1u : 0u);
+} MIRT_CATCH("mirt_tile_rows", return)
+
+int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes, mirt_buf* out, int root, int use_rccl) try {
+    if (!live_group(g)) return fail(nullptr, MIRT_E_HANDLE, "mirt_gather: unknown group");
+    const int n = (int)g->ctxs.size();
+    mirt_ctx* rc_ctx = g->ctxs[0];
+    if (!tiles || !tile_bytes || root < 0 || root >= n) return fail(rc_ctx, MIRT_E_ARG, "mirt_gather: null argument or root out of range");
+    mirt_ctx* rootc = g->ctxs[root];
+    uint64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!live_has(tiles[i]) || tiles[i]->ctx != g->ctxs[i]) return fail(rc_ctx, MIRT_E_HANDLE, "mirt_gather: tile %d is not a live buffer of the group's context %d", i, i);
+        if (tiles[i]->bytes < tile_bytes[i]) return fail(rc_ctx, MIRT_E_RANGE, "mirt_gather: tile %d holds %zu bytes, asked to send %zu", i, tiles[i]->bytes, tile_bytes[i]);
+        total += tile_bytes[i];
+    }
+    if (!live_has(out) || out->ctx != rootc) return fail(rc_ctx, MIRT_E_HANDLE, "mirt_gather: the output is not a live buffer of the root context");
+    if (out->bytes < total) return fail(rc_ctx, MIRT_E_RANGE, "mirt_gather: output holds %zu bytes, the tiles add up to %llu", out->bytes, (unsigned long long)total);
+    for (auto* c : g->ctxs) NOT_WHILE_CAPTURING(c, "mirt_gather");
+    if (n == 1 && !use_rccl) {   // tile == frame: one copy on the one device
+        HIPCHK(rootc, hipSetDevice(rootc->device));
+        if (tile_bytes[0]) HIPCHK(rootc, hipMemcpyAsync(out->ptr, tiles[0]->ptr, tile_bytes[0], hipMemcpyDeviceToDevice, rootc->stream));
+        out->version++;
+        return MIRT_OK;
+    }
+    int rc = group_comms(g);
+    if (rc) return rc;
+    Rccl& R = rccl();
+    // one grouped exchange: every device sends its tile to the root (the root's own tile included: a self send/recv pair is legal
+    // inside a group), the root receives each at that tile's offset.  N - 1 peers -> N - 1 distinct xGMI links into the root.
+    int nrc = R.GroupStart();
+    uint64_t off = 0;
+    for (int i = 0; i < n && nrc == 0; ++i) {
+        if (tile_bytes[i]) {
+            nrc = R.Send(tiles[i]->ptr, tile_bytes[i], kNcclUint8, root, g->comms[i], g->ctxs[i]->stream);
+            if (nrc == 0) nrc = R.Recv((char*)out->ptr + off, tile_bytes[i], kNcclUint8, i, g->comms[root], rootc->stream);
+        }
+        off += tile_bytes[i];
+    }
+    const int erc = R.GroupEnd();
+    if (nrc == 0) nrc = erc;
+    if (nrc != 0) return fail(rc_ctx, MIRT_E_DEVICE, "mirt_gather: RCCL: %s", R.GetErrorString(nrc));
+    out->version++;
+    return MIRT_OK;
+} MIRT_CATCH("mirt_gather", return MIRT_E_DEVICE)
+
+int mirt_group_finish(mirt_group* g) try {
+    if (!live_group(g)) return fail(nullptr, MIRT_E_HANDLE, "mirt_group_finish: unknown group");
+    for (auto* c : g->ctxs) {
+        NOT_WHILE_CAPTURING(c, "mirt_group_finish");
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MIRT_OK;
+} MIRT_CATCH("mirt_group_finish", return MIRT_E_DEVICE)
+
+const char* mirt_last_error(mirt_ctx* ctx) try {
+    if (ctx && live_has(ctx)) return ctx->last_error.c_str();
+    return t_last_error.c_str();
+} MIRT_CATCH("mirt_last_error", return "")
+
+int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_stream: unknown context");
     NOT_WHILE_CAPTURING(ctx, "mirt_ctx_set_stream");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_ctx_set_stream", return MIRT_E_DEVICE)
 
-int mirt_finish(mirt_ctx* ctx) {
+int mirt_finish(mirt_ctx* ctx) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_finish: unknown context");
     NOT_WHILE_CAPTURING(ctx, "mirt_finish");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_finish", return MIRT_E_DEVICE)
 
-int mirt_buf_create(mirt_ctx* ctx, size_t bytes, unsigned flags, mirt_buf** out) {
+int mirt_buf_create(mirt_ctx* ctx, size_t bytes, unsigned flags, mirt_buf** out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_create: unknown context");
     if (!out) return fail(ctx, MIRT_E_ARG, "mirt_buf_create: null out");
     *out = nullptr;
@@ -337,45 +594,41 @@ int mirt_buf_create(mirt_ctx* ctx, size_t bytes, unsigned flags, mirt_buf** out)
     void* p = nullptr;
     HIPCHK(ctx, hipMalloc(&p, bytes));
     mirt_buf* b = new mirt_buf();
-    b->ctx = ctx; b->ptr = p; b->bytes = bytes; b->owned = true; b->flags = flags;
-    live_add(b);
+    b->ctx = ctx; b->ptr = p; b->bytes = bytes; b->owned = true; b->flags = flags; b->uid = g_next_uid++;
+    live_add(b, H_BUF);
+    ctx->bufs.insert(b);
     *out = b;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_buf_create", return MIRT_E_DEVICE)
 
-int mirt_buf_wrap(mirt_ctx* ctx, void* device_ptr, size_t bytes, mirt_buf** out) {
+int mirt_buf_wrap(mirt_ctx* ctx, void* device_ptr, size_t bytes, mirt_buf** out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_wrap: unknown context");
     if (!out || !device_ptr || bytes == 0) return fail(ctx, MIRT_E_ARG, "mirt_buf_wrap: null pointer or zero size");
     if (((uintptr_t)device_ptr & 15u) != 0) return fail(ctx, MIRT_E_ARG, "mirt_buf_wrap: device pointer must be 16-byte aligned");
     mirt_buf* b = new mirt_buf();
-    b->ctx = ctx; b->ptr = device_ptr; b->bytes = bytes; b->owned = false; b->flags = MIRT_MEM_READ_WRITE;
-    live_add(b);
+    b->ctx = ctx; b->ptr = device_ptr; b->bytes = bytes; b->owned = false; b->flags = MIRT_MEM_READ_WRITE; b->uid = g_next_uid++;
+    live_add(b, H_BUF);
+    ctx->bufs.insert(b);
     *out = b;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_buf_wrap", return MIRT_E_DEVICE)
 
-int mirt_buf_release(mirt_buf* buf) {
+int mirt_buf_release(mirt_buf* buf) try {
     if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_release: unknown or already released buffer");
-    mirt_ctx* ctx = buf->ctx;
-    live_del(buf);
-    if (buf->owned && live_has(ctx)) {
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(buf->ptr);
-    }
-    if (buf->prep && live_has(ctx)) {
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(buf->prep);
-    }
-    delete buf;
+    free_buf(buf, live_has(buf->ctx));
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_buf_release", return MIRT_E_DEVICE)
 
-size_t mirt_buf_size(const mirt_buf* buf) { return live_has(buf) ? buf->bytes : 0; }
-void* mirt_buf_device_ptr(const mirt_buf* buf) { return live_has(buf) ? buf->ptr : nullptr; }
+int mirt_buf_invalidate(mirt_buf* buf) try {
+    if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_invalidate: unknown buffer");
+    buf->version++;
+    return MIRT_OK;
+} MIRT_CATCH("mirt_buf_invalidate", return MIRT_E_DEVICE)
 
-int mirt_buf_write(mirt_buf* buf, size_t offset, size_t nbytes, const void* host, int blocking) {
+size_t mirt_buf_size(const mirt_buf* buf) try { return live_has(buf) ? buf->bytes : 0; } MIRT_CATCH("mirt_buf_size", return 0)
+void* mirt_buf_device_ptr(const mirt_buf* buf) try { return live_has(buf) ? buf->ptr : nullptr; } MIRT_CATCH("mirt_buf_device_ptr", return nullptr)
+
+int mirt_buf_write(mirt_buf* buf, size_t offset, size_t nbytes, const void* host, int blocking) try {
     (void)blocking;
     if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_write: unknown buffer");
     mirt_ctx* ctx = buf->ctx;
@@ -389,9 +642,9 @@ int mirt_buf_write(mirt_buf* buf, size_t offset, size_t nbytes, const void* host
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the host array is borrowed for this call only
     buf->version++;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_buf_write", return MIRT_E_DEVICE)
 
-int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* host, int blocking) {
+int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* host, int blocking) try {
     (void)blocking;
     if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_read: unknown buffer");
     mirt_ctx* ctx = buf->ctx;
@@ -404,7 +657,7 @@ int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* host, int b
     HIPCHK(ctx, hipMemcpyAsync(host, (const char*)buf->ptr + offset, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_buf_read", return MIRT_E_DEVICE)
 
 // OpenCL C text with comments blanked out, and the names of its `__kernel void NAME(` definitions
 static void scan_source(const char* source, std::string* code, std::vector<std::string>* kernels) {
@@ -429,7 +682,7 @@ static void scan_source(const char* source, std::string* code, std::vector<std::
     }
 }
 
-int mirt_program_dialect(const char* source) {
+int mirt_program_dialect(const char* source) try {
     if (!source) return 0;
     std::string code;
     std::vector<std::string> ks;
@@ -445,9 +698,9 @@ int mirt_program_dialect(const char* source) {
     }
     if (ks.size() == 1 && ks[0] == "raytrace" && !text("__global float4")) return 1;   // A02's raytrace takes atom arrays
     return 0;
-}
+} MIRT_CATCH("mirt_program_dialect", return MIRT_E_DEVICE)
 
-int mirt_program_check(mirt_ctx* ctx, const char* source, char* missing, size_t cap) {
+int mirt_program_check(mirt_ctx* ctx, const char* source, char* missing, size_t cap) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_program_check: unknown context");
     if (!source) return fail(ctx, MIRT_E_ARG, "mirt_program_check: null source");
     std::string code, miss;
@@ -463,9 +716,9 @@ int mirt_program_check(mirt_ctx* ctx, const char* source, char* missing, size_t 
     }
     if (missing && cap) snprintf(missing, cap, "%s", miss.c_str());
     return n_missing;
-}
+} MIRT_CATCH("mirt_program_check", return MIRT_E_DEVICE)
 
-int mirt_kernel_get(mirt_ctx* ctx, const char* name, mirt_kernel** out) {
+int mirt_kernel_get(mirt_ctx* ctx, const char* name, mirt_kernel** out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_kernel_get: unknown context");
     if (!name || !out) return fail(ctx, MIRT_E_ARG, "mirt_kernel_get: null argument");
     *out = nullptr;
@@ -473,25 +726,25 @@ int mirt_kernel_get(mirt_ctx* ctx, const char* name, mirt_kernel** out) {
         if (strcmp(name, s.name) == 0) {
             mirt_kernel* k = new mirt_kernel();
             k->ctx = ctx; k->spec = &s; k->args.resize(s.args.size());
-            live_add(k);
+            live_add(k, H_KERNEL);
+            ctx->kernels.insert(k);
             *out = k;
             return MIRT_OK;
         }
     }
     return fail(ctx, MIRT_E_NAME, "no kernel named '%s' (INVALID_KERNEL_NAME)", name);
-}
+} MIRT_CATCH("mirt_kernel_get", return MIRT_E_DEVICE)
 
-int mirt_kernel_release(mirt_kernel* k) {
+int mirt_kernel_release(mirt_kernel* k) try {
     if (!live_has(k)) return fail(nullptr, MIRT_E_HANDLE, "mirt_kernel_release: unknown or already released kernel");
-    live_del(k);
-    delete k;
+    free_kernel(k, live_has(k->ctx));
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_kernel_release", return MIRT_E_DEVICE)
 
-int mirt_kernel_num_args(const mirt_kernel* k) { return live_has(k) ? (int)k->spec->args.size() : MIRT_E_HANDLE; }
-int mirt_kernel_preferred_multiple(const mirt_kernel* k) { return live_has(k) ? 64 : MIRT_E_HANDLE; }
+int mirt_kernel_num_args(const mirt_kernel* k) try { return live_has(k) ? (int)k->spec->args.size() : MIRT_E_HANDLE; } MIRT_CATCH("mirt_kernel_num_args", return MIRT_E_DEVICE)
+int mirt_kernel_preferred_multiple(const mirt_kernel* k) try { return live_has(k) ? 64 : MIRT_E_HANDLE; } MIRT_CATCH("mirt_kernel_preferred_multiple", return MIRT_E_DEVICE)
 
-int mirt_kernel_set_arg(mirt_kernel* k, unsigned index, size_t size, const void* value) {
+int mirt_kernel_set_arg(mirt_kernel* k, unsigned index, size_t size, const void* value) try {
     if (!live_has(k)) return fail(nullptr, MIRT_E_HANDLE, "mirt_kernel_set_arg: unknown kernel");
     mirt_ctx* ctx = k->ctx;
     if (index >= k->args.size()) return fail(ctx, MIRT_E_ARG, "%s: argument index %u out of range (%zu args)", k->spec->name, index, k->args.size());
@@ -502,9 +755,9 @@ int mirt_kernel_set_arg(mirt_kernel* k, unsigned index, size_t size, const void*
     memcpy(&k->args[index].val, value, size);
     k->args[index].set = true;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_kernel_set_arg", return MIRT_E_DEVICE)
 
-int mirt_kernel_set_arg_buf(mirt_kernel* k, unsigned index, mirt_buf* buf) {
+int mirt_kernel_set_arg_buf(mirt_kernel* k, unsigned index, mirt_buf* buf) try {
     if (!live_has(k)) return fail(nullptr, MIRT_E_HANDLE, "mirt_kernel_set_arg_buf: unknown kernel");
     mirt_ctx* ctx = k->ctx;
     if (index >= k->args.size()) return fail(ctx, MIRT_E_ARG, "%s: argument index %u out of range", k->spec->name, index);
@@ -514,9 +767,9 @@ int mirt_kernel_set_arg_buf(mirt_kernel* k, unsigned index, mirt_buf* buf) {
     k->args[index].buf = buf;
     k->args[index].set = true;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_kernel_set_arg_buf", return MIRT_E_DEVICE)
 
-int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* global, const size_t* local) {
+int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* global, const size_t* local) try {
     (void)local;  // no kernel uses local memory or barriers: the work-group shape is ours to choose
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_enqueue: unknown context");
     if (!live_has(k) || k->ctx != ctx) return fail(ctx, MIRT_E_HANDLE, "mirt_enqueue: unknown kernel");
@@ -525,6 +778,7 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
     for (size_t i = 0; i < k->args.size(); ++i) {
         if (!k->args[i].set) return fail(ctx, MIRT_E_UNSET, "%s: argument %zu was never set (INVALID_KERNEL_ARGS)", S.name, i);
         if (S.args[i] == A_BUF && !live_has(k->args[i].buf)) return fail(ctx, MIRT_E_HANDLE, "%s: argument %zu: buffer was released", S.name, i);
+        if (S.args[i] == A_BUF) pin(ctx, k->args[i].buf, false);
     }
     for (unsigned d = 0; d < dim; ++d)
         if (global[d] > 0xFFFFFFFFull) return fail(ctx, MIRT_E_ARG, "%s: global size exceeds 2^32", S.name);
@@ -710,7 +964,7 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
 #undef V
     HIPCHK(ctx, hipGetLastError());
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_enqueue", return MIRT_E_DEVICE)
 
 static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool tri, bool per_prim_matid, pt::GridArgs* o) {
     if (!g->prims || !g->cell_offsets) return fail(ctx, MIRT_E_ARG, "%s: null geometry buffer", what);
@@ -818,9 +1072,11 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
         if (ctx->defer_bytes < need_bytes) {
             NOT_WHILE_CAPTURING(ctx, "growing the deferred-sample mask");
             if (ctx->defer) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->defer)); ctx->defer = nullptr; ctx->defer_bytes = 0; }
+            ctx->defer_gen++;
             HIPCHK(ctx, hipMalloc(&ctx->defer, need_bytes));
             ctx->defer_bytes = need_bytes;
         }
+        if (ctx->capturing) ctx->cap_defer = true;
         uint32_t* mask = (uint32_t*)ctx->defer + 4;
         HIPCHK(ctx, hipMemsetAsync(ctx->defer, 0, need_bytes, ctx->stream));
         pt::launch_fused(ctx->stream, A, true, mask, nullptr, 0);
@@ -843,16 +1099,16 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     return MIRT_OK;
 }
 
-int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) { return render_pass_impl(ctx, d, false); }
-int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* d) { return render_pass_impl(ctx, d, true); }
+int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) try { return render_pass_impl(ctx, d, false); } MIRT_CATCH("mirt_render_pass", return MIRT_E_DEVICE)
+int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* d) try { return render_pass_impl(ctx, d, true); } MIRT_CATCH("mirt_render_first_pass", return MIRT_E_DEVICE)
 
-int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on) {
+int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_exact_only: unknown context");
     ctx->force_exact = on != 0;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_ctx_set_exact_only", return MIRT_E_DEVICE)
 
-int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) {
+int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_pass_deferred: unknown context");
     NOT_WHILE_CAPTURING(ctx, "mirt_pass_deferred");
     if (!samples) return fail(ctx, MIRT_E_ARG, "mirt_pass_deferred: null output");
@@ -868,16 +1124,16 @@ int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *samples = count;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_pass_deferred", return MIRT_E_DEVICE)
 
-int mirt_ctx_set_profiling(mirt_ctx* ctx, int on) {
+int mirt_ctx_set_profiling(mirt_ctx* ctx, int on) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_profiling: unknown context");
     ctx->profiling = on != 0;
     ctx->pe_valid = false;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_ctx_set_profiling", return MIRT_E_DEVICE)
 
-int mirt_pass_timing(mirt_ctx* ctx, float* fused_ms, float* resolve_ms) {
+int mirt_pass_timing(mirt_ctx* ctx, float* fused_ms, float* resolve_ms) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_pass_timing: unknown context");
     if (!ctx->pe_valid) return fail(ctx, MIRT_E_ARG, "mirt_pass_timing: no profiled mirt_render_pass yet (mirt_ctx_set_profiling)");
     HIPCHK(ctx, hipEventSynchronize(ctx->pe[2]));
@@ -887,9 +1143,9 @@ int mirt_pass_timing(mirt_ctx* ctx, float* fused_ms, float* resolve_ms) {
     if (fused_ms) *fused_ms = a;
     if (resolve_ms) *resolve_ms = b;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_pass_timing", return MIRT_E_DEVICE)
 
-int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, uint64_t count, uint32_t seed_base) {
+int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, uint64_t count, uint32_t seed_base) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_seed_fill: unknown context");
     int rc = need(ctx, "mirt_seed_fill", seeds, count * 4);
     if (rc) return rc;
@@ -898,9 +1154,9 @@ int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, uint64_t 
     HIPCHK(ctx, hipGetLastError());
     seeds->version++;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_seed_fill", return MIRT_E_DEVICE)
 
-int mirt_zero(mirt_ctx* ctx, mirt_buf* buf) {
+int mirt_zero(mirt_ctx* ctx, mirt_buf* buf) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_zero: unknown context");
     int rc = need(ctx, "mirt_zero", buf, 0);
     if (rc) return rc;
@@ -908,9 +1164,9 @@ int mirt_zero(mirt_ctx* ctx, mirt_buf* buf) {
     HIPCHK(ctx, hipMemsetAsync(buf->ptr, 0, buf->bytes, ctx->stream));
     buf->version++;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_zero", return MIRT_E_DEVICE)
 
-int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n) {
+int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_numerics: unknown context");
     int rc;
     if ((rc = need(ctx, "mirt_debug_numerics a", a, (uint64_t)n * 4))) return rc;
@@ -922,13 +1178,13 @@ int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_bu
     pt::launch_numerics(ctx->stream, op, a->ptr, b ? b->ptr : nullptr, out->ptr, n);
     HIPCHK(ctx, hipGetLastError());
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_debug_numerics", return MIRT_E_DEVICE)
 
 static int new_owned(mirt_ctx* ctx, size_t bytes, mirt_buf** out) {
     return mirt_buf_create(ctx, bytes ? bytes : 16, MIRT_MEM_READ_WRITE, out);
 }
 
-int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cell_offsets, mirt_buf** order, uint32_t* total) {
+int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cell_offsets, mirt_buf** order, uint32_t* total) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_build: unknown context");
     if (!d || d->struct_size != sizeof(mirt_grid_build_desc) || !cell_offsets || !order || !total)
         return fail(ctx, MIRT_E_ARG, "mirt_grid_build: null argument or descriptor size mismatch");
@@ -951,14 +1207,15 @@ int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cel
     }
     // adopt the order array as an owned buffer
     mirt_buf* ob = new mirt_buf();
-    ob->ctx = ctx; ob->bytes = *total ? (size_t)*total * 4 : 16; ob->owned = true; ob->flags = MIRT_MEM_READ_WRITE;
+    ob->ctx = ctx; ob->bytes = *total ? (size_t)*total * 4 : 16; ob->owned = true; ob->flags = MIRT_MEM_READ_WRITE; ob->uid = g_next_uid++;
     if (ord) ob->ptr = ord;
     else if (hipMalloc(&ob->ptr, 16) != hipSuccess) { delete ob; return fail(ctx, MIRT_E_DEVICE, "mirt_grid_build: hipMalloc failed"); }
-    live_add(ob);
+    live_add(ob, H_BUF);
+    ctx->bufs.insert(ob);
     *order = ob;
     (*cell_offsets)->version++;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_grid_build", return MIRT_E_DEVICE)
 
 int mirt_grid_gather_triangles(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* pos_f64, mirt_buf* nor_f64, uint32_t nsteps,
                                const int32_t* ops, const double* vecs, float pad_w, mirt_buf** pos_out, mirt_buf** nor_out) {
@@ -1001,7 +1258,7 @@ static int check_order(mirt_ctx* ctx, mirt_buf* order, uint32_t total, uint64_t 
     return MIRT_OK;
 }
 
-int mirt_grid_gather_spheres(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* sph_f64, mirt_buf** out) {
+int mirt_grid_gather_spheres(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* sph_f64, mirt_buf** out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_spheres: unknown context");
     if (!out) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_spheres: null out");
     int rc;
@@ -1014,9 +1271,9 @@ int mirt_grid_gather_spheres(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mir
     HIPCHK(ctx, hipGetLastError());
     (*out)->version++;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_grid_gather_spheres", return MIRT_E_DEVICE)
 
-int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* in_u32, mirt_buf** out) {
+int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* in_u32, mirt_buf** out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_u32: unknown context");
     if (!out) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_u32: null out");
     int rc;
@@ -1029,9 +1286,9 @@ int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_bu
     HIPCHK(ctx, hipGetLastError());
     (*out)->version++;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_grid_gather_u32", return MIRT_E_DEVICE)
 
-int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16) {
+int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_divcheck: unknown context");
     int rc = need(ctx, "mirt_debug_divcheck out", out16, 16 * 8);
     if (rc) return rc;
@@ -1043,18 +1300,20 @@ int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, 
     pt::launch_divCheck(ctx->stream, mode, seed, count, out16->ptr);
     HIPCHK(ctx, hipGetLastError());
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_debug_divcheck", return MIRT_E_DEVICE)
 
-int mirt_capture_begin(mirt_ctx* ctx) {
+int mirt_capture_begin(mirt_ctx* ctx) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_capture_begin: unknown context");
     if (ctx->capturing) return fail(ctx, MIRT_E_ARG, "mirt_capture_begin: already recording");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
     ctx->capturing = true;
+    ctx->cap_pins.clear();
+    ctx->cap_scratch = ctx->cap_defer = false;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_capture_begin", return MIRT_E_DEVICE)
 
-int mirt_capture_end(mirt_ctx* ctx, mirt_graph** out) {
+int mirt_capture_end(mirt_ctx* ctx, mirt_graph** out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_capture_end: unknown context");
     if (!out) return fail(ctx, MIRT_E_ARG, "mirt_capture_end: null output");
     if (!ctx->capturing) return fail(ctx, MIRT_E_ARG, "mirt_capture_end: not recording");
@@ -1073,39 +1332,48 @@ int mirt_capture_end(mirt_ctx* ctx, mirt_graph** out) {
     }
     mirt_graph* mg = new mirt_graph;
     mg->ctx = ctx; mg->graph = g; mg->exec = x;
-    live_add(mg);
+    mg->pins.swap(ctx->cap_pins);
+    mg->scratch_gen = ctx->cap_scratch ? ctx->scratch_gen : 0;
+    mg->defer_gen = ctx->cap_defer ? ctx->defer_gen : 0;
+    live_add(mg, H_GRAPH);
+    ctx->graphs.insert(mg);
     *out = mg;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_capture_end", return MIRT_E_DEVICE)
 
-int mirt_graph_launch(mirt_ctx* ctx, mirt_graph* graph) {
+int mirt_graph_launch(mirt_ctx* ctx, mirt_graph* graph) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_graph_launch: unknown context");
     if (!live_has(graph) || graph->ctx != ctx) return fail(ctx, MIRT_E_HANDLE, "mirt_graph_launch: unknown graph");
     NOT_WHILE_CAPTURING(ctx, "mirt_graph_launch");
+    // the recording holds raw device pointers: refuse to replay once any of them has been freed, replaced or (for validated /
+    // prepared geometry) rewritten since -- record the sequence again
+    for (const auto& p : graph->pins) {
+        if (!live_has(p.buf) || p.buf->uid != p.uid)
+            return fail(ctx, MIRT_E_HANDLE, "mirt_graph_launch: a buffer the recording uses has been released; record the sequence again");
+        if (p.content && (p.buf->version != p.version || p.buf->prep_gen != p.prep_gen))
+            return fail(ctx, MIRT_E_HANDLE, "mirt_graph_launch: geometry the recording was validated against has been rewritten; record the sequence again");
+    }
+    if ((graph->scratch_gen && graph->scratch_gen != ctx->scratch_gen) || (graph->defer_gen && graph->defer_gen != ctx->defer_gen))
+        return fail(ctx, MIRT_E_HANDLE, "mirt_graph_launch: the context's scratch memory was reallocated after the recording; record the sequence again");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipGraphLaunch(graph->exec, ctx->stream));
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_graph_launch", return MIRT_E_DEVICE)
 
-int mirt_graph_release(mirt_graph* graph) {
+int mirt_graph_release(mirt_graph* graph) try {
     if (!live_has(graph)) return fail(nullptr, MIRT_E_HANDLE, "mirt_graph_release: unknown graph");
-    mirt_ctx* ctx = graph->ctx;
-    if (live_has(ctx)) (void)hipStreamSynchronize(ctx->stream);
-    (void)hipGraphExecDestroy(graph->exec);
-    (void)hipGraphDestroy(graph->graph);
-    live_del(graph);
-    delete graph;
+    free_graph(graph, live_has(graph->ctx));
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_graph_release", return MIRT_E_DEVICE)
 
-int mirt_timer_start(mirt_ctx* ctx) {
+int mirt_timer_start(mirt_ctx* ctx) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_timer_start: unknown context");
     NOT_WHILE_CAPTURING(ctx, "mirt_timer_start");
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_timer_start", return MIRT_E_DEVICE)
 
-int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms) {
+int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_timer_stop_ms: unknown context");
     NOT_WHILE_CAPTURING(ctx, "mirt_timer_stop_ms");
     if (!ms) return fail(ctx, MIRT_E_ARG, "mirt_timer_stop_ms: null output");
@@ -1113,6 +1381,6 @@ int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms) {
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_timer_stop_ms", return MIRT_E_DEVICE)
 
 }  // extern "C"

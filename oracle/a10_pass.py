@@ -60,6 +60,12 @@ def _f(a):
 class CpuKernels:
     """ctypes view of one CPU implementation (ref or oracle)."""
 
+    on_gpu = False
+    buf = staticmethod(_p)      # a kernel argument for a numpy buffer: its host pointer
+
+    def flush(self):            # (oracle/ref_gpu.py copies its device mirrors back here)
+        pass
+
     def __init__(self, path, prefix):
         self.lib = C.CDLL(path)
         self.prefix = prefix
@@ -90,8 +96,28 @@ class CpuKernels:
             setattr(self, name, fn)
 
 
+_HW = []
+
+
+def set_hw_tables(lib, prefix):
+    """Hands a CPU checker the measured v_rsq_f32 / v_sqrt_f32 tables of the MI355X (oracle/hw_tables.bin.z, made by
+    oracle/probe/hw_probe.hip + make_hw_tables.py): int8[2^24] each.  cl_numerics.h aborts without them."""
+    import zlib
+    if not _HW:
+        raw = zlib.decompress(open(os.path.join(HERE, "hw_tables.bin.z"), "rb").read())
+        assert len(raw) == 2 << 24
+        _HW.append(C.create_string_buffer(raw, len(raw)))
+    fn = getattr(lib, prefix + "set_hw_tables")
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    fn.restype = None
+    base = C.addressof(_HW[0])
+    fn(base, base + (1 << 24))
+
+
 def load_ref():
-    return CpuKernels(os.path.join(HERE, "_ref", "libref_a10.so"), "ref_a10_")
+    k = CpuKernels(os.path.join(HERE, "_ref", "libref_a10.so"), "ref_a10_")
+    set_hw_tables(k.lib, "ref_")
+    return k
 
 
 def cpu_budget():
@@ -118,6 +144,7 @@ def load_oracle():
     k.lib.oracle_set_threads.argtypes = [C.c_int]
     k.lib.oracle_set_threads.restype = None
     k.lib.oracle_set_threads(cpu_budget())
+    set_hw_tables(k.lib, "oracle_")
     return k
 
 
@@ -176,58 +203,62 @@ def run_pass(k, sc, st, bounces=5, checkpoints=None, init_acu=True):
     receives snapshots after the primary segment ('primary') and each bounce."""
     n = sc.total_rays
     g1 = _ceil(n, WAVE)
+    B = k.buf          # host pointer (CPU kernels) or device mirror (oracle/ref_gpu.py)
     if init_acu:  # preRender -> prepareInitAcu (code.js:1078-1099), once per render
-        k.initAcu(_p(st.acu), n, g1)
+        k.initAcu(B(st.acu), n, g1)
 
     bp, _b = _f(sc.bounds)
     cp, _c = _f(sc.cam)
     # getLocalWS(2, ...) with a multiple of 64 -> [8, 8]  (code.js:661-663)
-    k.initTrace(_p(st.seeds), _p(st.rays), _p(st.pois), bp, cp, sc.focal_length, sc.lens_rad, sc.rpp,
+    k.initTrace(B(st.seeds), B(st.rays), B(st.pois), bp, cp, sc.focal_length, sc.lens_rad, sc.rpp,
                 _ceil(sc.width, 8), _ceil(sc.height, 8))
 
     def closest():
         if sc.has_spheres:
             p, _k = _f(sc.sphere_bounds)
-            k.sphereTrace(n, _p(st.pois), _p(st.rays), _p(sc.spheres), _p(sc.s_matid), _p(sc.s_box), p, sc.n_slabs, g1)
+            k.sphereTrace(n, B(st.pois), B(st.rays), B(sc.spheres), B(sc.s_matid), B(sc.s_box), p, sc.n_slabs, g1)
         if sc.has_triangles:
             p, _k = _f(sc.triangle_bounds)
-            k.triangleTrace(n, _p(st.pois), _p(st.rays), _p(sc.t_pos), _p(sc.t_normal), _p(sc.t_matid), _p(sc.t_box), p, sc.n_slabs, g1)
+            k.triangleTrace(n, B(st.pois), B(st.rays), B(sc.t_pos), B(sc.t_normal), B(sc.t_matid), B(sc.t_box), p, sc.n_slabs, g1)
         for m in sc.meshes:
             p, _k = _f(m["bounds"])
-            k.meshTrace(n, _p(st.pois), _p(st.rays), _p(m["pos"]), _p(m["normal"]), _p(m["box"]), m["matid"], p, m["nslabs"], g1)
+            k.meshTrace(n, B(st.pois), B(st.rays), B(m["pos"]), B(m["normal"]), B(m["box"]), m["matid"], p, m["nslabs"], g1)
 
     def direct():
         for l in sc.lights:
             p, _k = _f(l["shadow"])
-            k.initShadowTrace(_p(st.shadow), _p(st.pois), n, p, _p(st.seeds), g1)
+            k.initShadowTrace(B(st.shadow), B(st.pois), n, p, B(st.seeds), g1)
             if sc.has_spheres:
                 p, _k = _f(sc.sphere_bounds)
-                k.sphereShadowTrace(n, _p(st.shadow), _p(sc.spheres), _p(sc.s_box), p, sc.n_slabs, g1)
+                k.sphereShadowTrace(n, B(st.shadow), B(sc.spheres), B(sc.s_box), p, sc.n_slabs, g1)
             if sc.has_triangles:
                 p, _k = _f(sc.triangle_bounds)
-                k.triangleShadowTrace(n, _p(st.shadow), _p(sc.t_pos), _p(sc.t_box), p, sc.n_slabs, g1)
+                k.triangleShadowTrace(n, B(st.shadow), B(sc.t_pos), B(sc.t_box), p, sc.n_slabs, g1)
             for m in sc.meshes:
                 p, _k = _f(m["bounds"])
-                k.triangleShadowTrace(n, _p(st.shadow), _p(m["pos"]), _p(m["box"]), p, m["nslabs"], g1)
+                k.triangleShadowTrace(n, B(st.shadow), B(m["pos"]), B(m["box"]), p, m["nslabs"], g1)
             p, _k = _f(l["scene"])
-            k.sceneRender(_p(st.acu), _p(st.pois), _p(st.shadow), _p(sc.materials), p, n, g1)
+            k.sceneRender(B(st.acu), B(st.pois), B(st.shadow), B(sc.materials), p, n, g1)
 
     closest()
     for l in sc.lights:
         p, _k = _f(l["light"])
-        k.lightRender(_p(st.pois), _p(st.rays), _p(st.acu), p, n, g1)
+        k.lightRender(B(st.pois), B(st.rays), B(st.acu), p, n, g1)
     direct()
     if checkpoints is not None:
+        k.flush()
         checkpoints["primary"] = st.snapshot()
     for j in range(bounces):
-        k.bouncePaths(_p(st.pois), _p(st.rays), _p(st.seeds), n, g1)
+        k.bouncePaths(B(st.pois), B(st.rays), B(st.seeds), n, g1)
         closest()
         direct()
         if checkpoints is not None and j == 0:
+            k.flush()
             checkpoints["bounce1"] = st.snapshot()
     m = np.float32(1.0 / (sc.rpp * st.passes))  # code.js:1412: double division, narrowed by Float32Array
-    k.copyToPixel(_p(st.pixel), _p(st.acu), float(m), sc.width * sc.height, sc.rpp, _ceil(sc.width * sc.height, WAVE))
+    k.copyToPixel(B(st.pixel), B(st.acu), float(m), sc.width * sc.height, sc.rpp, _ceil(sc.width * sc.height, WAVE))
     st.passes += 1
+    k.flush()
     return st
 
 

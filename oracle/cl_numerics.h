@@ -1,68 +1,192 @@
 /*
  * oracle/cl_numerics.h -- TEST INFRASTRUCTURE (checker only; never linked into the product).
  *
- * The numerics contract of the path, restated in plain C.  OpenCL C leaves the
- * accuracy (and therefore the bits) of its built-in math to the implementation
- * (OpenCL 1.2 spec section 7.4: x/y <= 2.5 ulp, sqrt <= 3 ulp, sin/cos <= 4 ulp,
- * mad "implementation defined", a*b+c may or may not be fused).  A bit-for-bit parity target only exists once
- * those are pinned; this header pins them:
+ * The numerics contract of the path: the OpenCL C built-ins exactly as AMD's own OpenCL toolchain evaluates them on
+ * gfx950 (MI355X), restated for a CPU.
  *
- *   + - *      IEEE-754 binary32, round-to-nearest-even, no contraction (no FMA)
- *   /, sqrt    correctly rounded
- *   mad(a,b,c) a*b + c, two roundings          (reference use: A10 code.cl:209)
- *   min/max    OpenCL common-function form: min(x,y) = y < x ? y : x;
- *              max(x,y) = x < y ? y : x         (code.cl:325-380, 550, 568, 748)
- *   fmin/fmax  IEEE minNum/maxNum (a NaN loses)  (code.cl:223-224)
- *   clamp      fmin(fmax(x, lo), hi)             (code.cl:1352-1353, 1383)
- *   dot        ((a.x*b.x) + (a.y*b.y)) + (a.z*b.z)
- *   cross      (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
- *   length     sqrt(dot(a,a));  distance(a,b) = length(a-b)
- *   normalize  a * (1.0f / sqrt(dot(a,a)))   (one division, three products)
- *   sin/cos    Cody-Waite 3-term pi/2 reduction + Cephes single-precision
- *              minimax polynomials, explicit evaluation order (below); <= 2 ulp
- *              on the only range the path uses, phi in [-pi/4, 3pi/4]
- *              (concentric_distort, code.cl:143-172).
+ * "The reference OpenCL output" is only defined once an OpenCL implementation is named (OpenCL 1.2 section 7.4 leaves the
+ * bits of /, sqrt, sin, cos, normalize ... and the fusing of a*b+c to the implementation).  The one named here is the one
+ * that exists for the target: the ROCm clang in OpenCL mode + AMD's OpenCL C built-in library
+ * (/opt/rocm/amdgcn/bitcode/opencl.bc, ocml.bc, ockl.bc -- what the ROCm OpenCL runtime links), build options
+ * `-cl-std=CL1.2 -O3 -cl-fp32-correctly-rounded-divide-sqrt`.  oracle/Makefile `ref_gpu` compiles the reference's code.cl
+ * that way into oracle/_ref/a10_gfx950.hsaco and oracle/ref_gpu.py runs it ON the MI355X: that binary is the pin, with no
+ * stand-ins.  This header is the CPU model of the same arithmetic; tests/test_ref_gpu.py proves model == device, function by
+ * function (oracle/probe/builtins.cl compiled by the same toolchain, millions of arguments, every special value) and
+ * kernel by kernel (every fixture).
  *
- * The HIP kernels implement the same contract in their own source
- * (2015-raytracing_amd/csrc/pt_numerics.hpp); nothing here is included there.
- * Compile every user of this header with -ffp-contract=off and without fast-math.
+ *   + - *        IEEE-754 binary32, round-to-nearest-even, denormals kept
+ *   a*b+c        FUSED (one rounding) wherever the OpenCL front end contracts: mul feeding an add/sub inside one expression
+ *                (clang -ffp-contract=on, the OpenCL default).  In the reference's text: oracle/README.md lists the 47 sites of
+ *                A10 code.cl (e.g. :87 r.o + t*r.d, :698 ray.o.x + tmin*ray.d.x, :568 1 - x*x - y*y); pt_oracle.c spells each
+ *                as cln_fma().  In the built-ins: below.
+ *   /, sqrt()    correctly rounded (-cl-fp32-correctly-rounded-divide-sqrt; OpenCL 1.2 section 5.6.4.2).  Without that option AMD's
+ *                division is a 2.5-ulp v_rcp_f32 sequence no CPU can reproduce; _ref/a10_gfx950_default.hsaco is that build,
+ *                kept to MEASURE how far two conformant builds drift apart.
+ *   mad(a,b,c)   fma(a,b,c)                                              (ocml.bc __ocml_mad_f32 -> llvm.fmuladd)
+ *   dot(a,b)     fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))                     (opencl.bc _Z3dotDv3_fS_)
+ *   cross(a,b)   x = fma(a.y,b.z, -(a.z*b.y)), y = fma(a.z,b.x, -(a.x*b.z)), z = fma(a.x,b.y, -(a.y*b.x))
+ *   length(v)    d = dot(v,v); d < 2^-126: 2^-86 * S(dot(2^86 v)); d == inf: 2^66 * S(dot(2^-66 v)); else S(d), where S is the
+ *                HARDWARE square root v_sqrt_f32 (the library asks for sqrt !fpmath 3.0), pre-scaled by 2^32 below 2^-126
+ *   distance     length(a - b)
+ *   normalize(v) v unchanged if all components are 0; else the same two rescalings as length, then v * R(d) with R the HARDWARE
+ *                reciprocal square root v_rsq_f32 (ocml rsqrt: pre-scaled by 2^24 below 2^-126, result * 2^12)
+ *   min max fmin fmax   llvm.minnum / maxnum = v_min_f32 / v_max_f32: a NaN loses, -0 < +0
+ *   clamp(x,lo,hi)      v_med3_f32: the median; with a NaN operand, the minimum of the others
+ *   sin cos      ocml's __ocml_sin_f32 / __ocml_cos_f32, small-argument path (|x| < 131072): n = rint(x * 2/pi), three-fma
+ *                Cody-Waite reduction, fused minimax polynomials.  NaN / inf -> NaN.  The Payne-Hanek path for larger finite
+ *                arguments is not restated: concentric_distort (A10 code.cl:143-172) only produces |phi| <= 3 pi / 4.
+ *   (int)f (uint)f   v_cvt_*: truncate, saturate, NaN -> 0
+ *
+ * v_sqrt_f32 and v_rsq_f32 are 1-ulp hardware approximations whose bits no document fixes.  oracle/probe/hw_probe.hip MEASURED
+ * them on the MI355X: for x = 2^e * 1.m the result is a function of (e mod 2, m) scaled by a power of two -- checked for all
+ * 2 139 095 039 positive finite floats, zero exceptions -- and differs from 1.0f/sqrtf(x) resp. sqrtf(x) (correctly rounded binary32 operations) by at most 2 ulp.
+ * oracle/hw_tables.bin.z holds those 2 x 2^24 deltas (zlib, 0.4 MB); cln_hw_tables() must be given them before first use.
+ *
+ * NaN payloads and signs are outside the contract (x86 and gfx950 propagate them differently): a NaN is a NaN.
+ * Compile every user with -ffp-contract=off (fusion is explicit here) and without fast-math.
  */
 #ifndef ORACLE_CL_NUMERICS_H
 #define ORACLE_CL_NUMERICS_H
 
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-static inline float cln_min(float x, float y) { return (y < x) ? y : x; }
-static inline float cln_max(float x, float y) { return (x < y) ? y : x; }
+static inline uint32_t cln_bits(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline float cln_float(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 
-static inline float cln_fmin(float x, float y) {
+static inline float cln_fma(float a, float b, float c) { return fmaf(a, b, c); }   /* one rounding */
+static inline float cln_mad(float a, float b, float c) { return fmaf(a, b, c); }
+
+/* v_min_f32 / v_max_f32 (IEEE mode): NaN loses, -0 < +0 */
+static inline float cln_minnum(float x, float y) {
     if (x != x) return y;
     if (y != y) return x;
+    if (x == y) return (cln_bits(x) & 0x80000000u) ? x : y;   /* +-0 */
     return (y < x) ? y : x;
 }
-static inline float cln_fmax(float x, float y) {
+static inline float cln_maxnum(float x, float y) {
     if (x != x) return y;
     if (y != y) return x;
+    if (x == y) return (cln_bits(x) & 0x80000000u) ? y : x;
     return (x < y) ? y : x;
 }
-static inline float cln_clamp(float x, float lo, float hi) { return cln_fmin(cln_fmax(x, lo), hi); }
-
-static inline float cln_fabs(float x) {
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    u &= 0x7fffffffu;
-    memcpy(&x, &u, 4);
-    return x;
+static inline float cln_min(float x, float y) { return cln_minnum(x, y); }
+static inline float cln_max(float x, float y) { return cln_maxnum(x, y); }
+static inline float cln_fmin(float x, float y) { return cln_minnum(x, y); }
+static inline float cln_fmax(float x, float y) { return cln_maxnum(x, y); }
+/* v_med3_f32 */
+static inline float cln_clamp(float x, float lo, float hi) {
+    if (x != x || lo != lo || hi != hi) return cln_minnum(cln_minnum(x, lo), hi);
+    return cln_maxnum(cln_minnum(x, lo), cln_minnum(cln_maxnum(x, lo), hi));
 }
 
+static inline float cln_fabs(float x) { return cln_float(cln_bits(x) & 0x7fffffffu); }
 static inline float cln_sqrt(float x) { return sqrtf(x); } /* correctly rounded (IEEE) */
-static inline float cln_mad(float a, float b, float c) { return a * b + c; }
+
+/* ---- the two hardware functions, from their measured tables ------------------------------------------------------------ */
+static const int8_t* cln_rsq_delta = 0;    /* [parity << 23 | mantissa] */
+static const int8_t* cln_sqrt_delta = 0;
+static inline void cln_hw_tables(const int8_t* rsq, const int8_t* sq) { cln_rsq_delta = rsq; cln_sqrt_delta = sq; }
+static inline void cln_need_tables(void) {
+    if (!cln_rsq_delta || !cln_sqrt_delta) { fprintf(stderr, "cl_numerics: hardware tables not loaded (oracle/hw_tables.bin.z -> *_set_hw_tables)\n"); abort(); }
+}
+/* x: positive, finite, normal.  x = 2^(2k+par) * 1.m */
+static inline float cln_hw_rsq_normal(float x) {
+    const uint32_t b = cln_bits(x);
+    const int e = (int)(b >> 23) - 127, par = e & 1, k = (e - par) / 2;
+    const float xm = cln_float(((127u + (uint32_t)par) << 23) | (b & 0x7FFFFFu));          /* in [1,4) */
+    const float base = 1.0f / sqrtf(xm);                                                    /* two correctly rounded binary32 operations */
+    const float t = cln_float(cln_bits(base) + (uint32_t)(int32_t)cln_rsq_delta[((uint32_t)par << 23) | (b & 0x7FFFFFu)]);
+    return ldexpf(t, -k);
+}
+static inline float cln_hw_sqrt_normal(float x) {
+    const uint32_t b = cln_bits(x);
+    const int e = (int)(b >> 23) - 127, par = e & 1, k = (e - par) / 2;
+    const float xm = cln_float(((127u + (uint32_t)par) << 23) | (b & 0x7FFFFFu));
+    const float base = sqrtf(xm);
+    const float t = cln_float(cln_bits(base) + (uint32_t)(int32_t)cln_sqrt_delta[((uint32_t)par << 23) | (b & 0x7FFFFFu)]);
+    return ldexpf(t, k);
+}
+/* ocml rsqrt(x): x < 2^-126 ? 4096 * v_rsq_f32(x * 2^24) : v_rsq_f32(x) */
+static inline float cln_rsqrt(float x) {
+    cln_need_tables();
+    if (x != x) return x;
+    const int tiny = x < 0x1p-126f;
+    const float xs = tiny ? x * 16777216.0f : x;
+    float r;
+    if (xs == 0.0f) r = (cln_bits(xs) & 0x80000000u) ? -INFINITY : INFINITY;
+    else if (xs < 0.0f) r = NAN;
+    else if (xs == INFINITY) r = 0.0f;
+    else r = cln_hw_rsq_normal(xs);
+    return tiny ? r * 4096.0f : r;
+}
+/* llvm.sqrt !fpmath 3.0 as the gfx950 back end lowers it: x < 2^-126 ? ldexp(v_sqrt_f32(ldexp(x, 32)), -16) : v_sqrt_f32(x) */
+static inline float cln_sqrt_approx(float x) {
+    cln_need_tables();
+    if (x != x) return x;
+    const int tiny = x < 0x1p-126f;
+    const float xs = tiny ? ldexpf(x, 32) : x;
+    float r;
+    if (xs == 0.0f) r = xs;
+    else if (xs < 0.0f) r = NAN;
+    else if (xs == INFINITY) r = INFINITY;
+    else r = cln_hw_sqrt_normal(xs);
+    return tiny ? ldexpf(r, -16) : r;
+}
+
+/* ---- geometric built-ins (opencl.bc) ------------------------------------------------------------------------------------ */
+static inline float cln_dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return cln_fma(az, bz, cln_fma(ay, by, ax * bx));
+}
+static inline void cln_cross3(const float* a, const float* b, float* r) {
+    const float x = cln_fma(a[1], b[2], -(a[2] * b[1]));
+    const float y = cln_fma(a[2], b[0], -(a[0] * b[2]));
+    const float z = cln_fma(a[0], b[1], -(a[1] * b[0]));
+    r[0] = x; r[1] = y; r[2] = z;
+}
+static inline float cln_length3(float x, float y, float z) {
+    const float d = cln_dot3(x, y, z, x, y, z);
+    if (d < 0x1p-126f) {
+        const float s = 0x1p+86f;
+        const float X = x * s, Y = y * s, Z = z * s;
+        return cln_sqrt_approx(cln_dot3(X, Y, Z, X, Y, Z)) * 0x1p-86f;
+    }
+    if (d == INFINITY) {
+        const float s = 0x1p-66f;
+        const float X = x * s, Y = y * s, Z = z * s;
+        return cln_sqrt_approx(cln_dot3(X, Y, Z, X, Y, Z)) * 0x1p+66f;
+    }
+    return cln_sqrt_approx(d);
+}
+static inline void cln_normalize3(const float* v, float* r) {
+    float x = v[0], y = v[1], z = v[2];
+    if (x == 0.0f && y == 0.0f && z == 0.0f) { r[0] = x; r[1] = y; r[2] = z; return; }
+    float d = cln_dot3(x, y, z, x, y, z);
+    if (d < 0x1p-126f) {
+        const float s = 0x1p+86f;
+        x *= s; y *= s; z *= s;
+        d = cln_dot3(x, y, z, x, y, z);
+    } else if (d == INFINITY) {
+        const float s = 0x1p-66f;
+        x *= s; y *= s; z *= s;
+        d = cln_dot3(x, y, z, x, y, z);
+        if (d == INFINITY) {
+            x = copysignf(isinf(x) ? 1.0f : 0.0f, x);
+            y = copysignf(isinf(y) ? 1.0f : 0.0f, y);
+            z = copysignf(isinf(z) ? 1.0f : 0.0f, z);
+            d = cln_dot3(x, y, z, x, y, z);
+        }
+    }
+    const float rs = cln_rsqrt(d);
+    r[0] = x * rs; r[1] = y * rs; r[2] = z * rs;
+}
 
 /* float -> int32 the way the device does it: truncate, saturate, NaN -> 0.
  * (The reference's (int)f at code.cl:700 etc. is UB in C outside the int range;
@@ -80,48 +204,37 @@ static inline uint32_t cln_f2u(float f) {
     return (uint32_t)f;
 }
 
-/* sin and cos share one argument reduction.  k = rint(x * 2/pi) by the
- * 1.5*2^23 trick (valid for |x*2/pi| < 2^22; beyond that the result is still
- * deterministic, just inaccurate -- the path never goes there). */
+/* ---- sin / cos (ocml.bc: __ocmlpriv_trigredsmall_f32, gfx9+ branch, and __ocmlpriv_sincosred_f32) --------------------------- */
 static inline void cln_sincos(float x, float* sn, float* cs) {
-    const float two_over_pi = 0.63661977236758134308f;
-    const float magic = 12582912.0f;      /* 1.5 * 2^23 */
-    const float pio2_hi = 1.5703125f;     /* 8 significant bits: k*hi exact */
-    const float pio2_md = 4.837512969970703125e-4f;
-    const float pio2_lo = 7.54978995489188216e-8f;
-
-    float kf = x * two_over_pi + magic; /* IEEE: not re-associable without fast-math */
-    kf = kf - magic;
-    int32_t q = (kf == kf) ? (int32_t)kf : 0;
-
-    float r = x - kf * pio2_hi;
-    r = r - kf * pio2_md;
-    r = r - kf * pio2_lo;
-    float r2 = r * r;
-
-    float sp = -1.9515295891e-4f * r2;
-    sp = sp + 8.3321608736e-3f;
-    sp = sp * r2;
-    sp = sp - 1.6666654611e-1f;
-    sp = sp * r2;
-    sp = sp * r;
-    float s = sp + r;
-
-    float cp = 2.443315711809948e-5f * r2;
-    cp = cp - 1.388731625493765e-3f;
-    cp = cp * r2;
-    cp = cp + 4.166664568298827e-2f;
-    cp = cp * r2;
-    cp = cp * r2;
-    float c = cp - 0.5f * r2;
-    c = c + 1.0f;
-
-    switch (q & 3) {
-        case 0: *sn = s;  *cs = c;  break;
-        case 1: *sn = c;  *cs = -s; break;
-        case 2: *sn = -s; *cs = -c; break;
-        default: *sn = -c; *cs = s; break;
+    const float ax = cln_fabs(x);
+    if (!(ax < INFINITY)) { *sn = NAN; *cs = NAN; return; }                 /* NaN, +-inf */
+    if (!(ax < 131072.0f)) {
+        fprintf(stderr, "cl_numerics: sin/cos of %g: the large-argument (Payne-Hanek) path of ocml is not restated\n", (double)x);
+        abort();
     }
+    /* constants: the float values of ocml.bc's IR, as hexadecimal literals */
+    const float n = rintf(ax * 0x1.45f306p-1f);                             /* 2/pi                     */
+    float r = cln_fma(n, -0x1.921fb4p+0f, ax);                              /* pi/2 in three pieces     */
+    r = cln_fma(n, -0x1.4442dp-24f, r);
+    r = cln_fma(n, -0x1.846988p-48f, r);
+    const int q = (int)n & 3;
+    const float s2 = r * r;
+    float sp = cln_fma(s2, -0x1.983304p-13f, 0x1.110388p-7f);
+    sp = cln_fma(s2, sp, -0x1.55553ap-3f);
+    const float s = cln_fma(r, s2 * sp, r);
+    float cp = cln_fma(s2, 0x1.aea668p-16f, -0x1.6c9e76p-10f);
+    cp = cln_fma(s2, cp, 0x1.5557eep-5f);
+    cp = cln_fma(s2, cp, -0x1.000008p-1f);
+    const float c = cln_fma(s2, cp, 1.0f);
+    /* sin: odd quadrants take the cosine polynomial; quadrants 2, 3 flip the sign; then the sign of x */
+    float sv = (q & 1) ? c : s;
+    if (q > 1) sv = -sv;
+    if (cln_bits(x) & 0x80000000u) sv = -sv;
+    /* cos: odd quadrants take -sin; quadrants 2, 3 flip */
+    float cv = (q & 1) ? -s : c;
+    if (q > 1) cv = -cv;
+    *sn = sv;
+    *cs = cv;
 }
 static inline float cln_sin(float x) { float s, c; cln_sincos(x, &s, &c); return s; }
 static inline float cln_cos(float x) { float s, c; cln_sincos(x, &s, &c); return c; }

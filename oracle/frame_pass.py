@@ -17,8 +17,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def _lib(kind, assign):
     if kind == "ref":
-        return C.CDLL(os.path.join(HERE, "_ref", f"libref_a{assign:02d}.so")), f"ref_a{assign:02d}_"
+        lib = C.CDLL(os.path.join(HERE, "_ref", f"libref_a{assign:02d}.so"))
+        A.set_hw_tables(lib, "ref_")
+        return lib, f"ref_a{assign:02d}_"
     lib = C.CDLL(os.path.join(HERE, "liboracle.so"))
+    A.set_hw_tables(lib, "oracle_")
     lib.oracle_set_threads.argtypes = [C.c_int]
     lib.oracle_set_threads.restype = None
     lib.oracle_set_threads(A.cpu_budget())      # threads = the CPUs this process may really use (cgroup quota), see a10_pass.cpu_budget

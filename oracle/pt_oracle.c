@@ -4,12 +4,19 @@
  * CPU restatement, in plain C, of the Assign10 path-tracing kernels of
  * eaymerich/2015-RayTracing.  Every function cites the reference lines it
  * follows ("A10 code.cl:NNN" = Assign10-Path_Tracing/code.cl).  Arithmetic
- * follows oracle/cl_numerics.h (IEEE binary32, no contraction, explicit
- * evaluation order); vector expressions are spelled out component-wise in the
- * order OpenCL C evaluates them (left to right, scalar*scalar before
- * scalar*vector where the source does so).
+ * follows oracle/cl_numerics.h: the reference as AMD's OpenCL toolchain builds it for
+ * gfx950.  That means (a) the built-ins are AMD's (fused dot / cross, hardware
+ * rsq / sqrt in normalize / length, v_min / v_max / v_med3) and (b) a*b+c is FUSED
+ * wherever the OpenCL front end contracts it: a multiplication that feeds an
+ * addition or subtraction inside one expression (the left operand first when both
+ * are products).  The sites in the reference's text (A10 code.cl:87, 111, 152, 153,
+ * 164, 190, 410, 568, 574, 659, 666, 698-732 and its four copies; oracle/README.md
+ * has the list and how it was obtained) are spelled fma3 / cln_fma below; everything
+ * else is separate IEEE operations, component-wise, in the order OpenCL C evaluates
+ * them.
  *
- * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no fast-math).
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no fast-math: fusion is
+ * explicit).
  */
 #include "pt_oracle.h"
 #include "cl_numerics.h"
@@ -64,23 +71,27 @@ static inline v3 add(v3 a, v3 b) { FL(3); return V(a.x + b.x, a.y + b.y, a.z + b
 static inline v3 sub(v3 a, v3 b) { FL(3); return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 mulv(v3 a, v3 b) { FL(3); return V(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 scl(float s, v3 a) { FL(3); return V(s * a.x, s * a.y, s * a.z); }
-static inline float dot3(v3 a, v3 b) {
-    FL(5);
-    float s = a.x * b.x;
-    s = s + a.y * b.y;
-    s = s + a.z * b.z;
-    return s;
-}
+/* s*a + c with ONE rounding per component: where the OpenCL front end contracts (see the header comment) */
+static inline v3 fma3(float s, v3 a, v3 c) { FL(6); return V(cln_fma(s, a.x, c.x), cln_fma(s, a.y, c.y), cln_fma(s, a.z, c.z)); }
+/* the geometric built-ins: AMD's definitions (cl_numerics.h) */
+static inline float dot3(v3 a, v3 b) { FL(5); return cln_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 static inline v3 cross3(v3 a, v3 b) {
     FL(9);
-    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    const float A[3] = {a.x, a.y, a.z}, B[3] = {b.x, b.y, b.z};
+    float r[3];
+    cln_cross3(A, B, r);
+    return V(r[0], r[1], r[2]);
 }
-static inline float len3(v3 a) { FL(1); return cln_sqrt(dot3(a, a)); }
+static inline float len3(v3 a) { FL(6); return cln_length3(a.x, a.y, a.z); }
 static inline v3 norm3(v3 a) {
-    FL(5);
-    float inv = 1.0f / cln_sqrt(dot3(a, a));
-    return V(a.x * inv, a.y * inv, a.z * inv);
+    FL(9);
+    const float A[3] = {a.x, a.y, a.z};
+    float r[3];
+    cln_normalize3(A, r);
+    return V(r[0], r[1], r[2]);
 }
+/* getPoint, A10 code.cl:86-88: r.o + t * r.d, contracted */
+static inline v3 get_point(v3 o, float t, v3 d) { return fma3(t, d, o); }
 
 #define PT_INF (__builtin_inff())
 #define PI_4_F 0.785398163397448309616f
@@ -126,7 +137,8 @@ static ray_t get_ray(const cam_t* c, float col, float row) {
     FL(8);
     float sx = (-0.5f + (col + 0.5f) / (float)c->cols) * c->width;
     float sy = (0.5f - (row + 0.5f) / (float)c->rows) * c->height;
-    v3 cop = add(add(scl(sx, c->U), scl(sy, c->V)), scl(-1.0f, c->W));
+    /* sx*U + sy*V + (-1)*W: the first sum takes its LEFT product fused, fma(sx, U, sy*V); the second is fma(-1, W, .) = exact */
+    v3 cop = add(fma3(sx, c->U, scl(sy, c->V)), scl(-1.0f, c->W));
     ray_t r;
     r.d = norm3(cop);
     r.o = c->eye;
@@ -140,8 +152,8 @@ static void concentric(float inx, float iny, float* ox, float* oy) {
     if (inx == 0.0f && iny == 0.0f) { *ox = inx; *oy = iny; return; }
     float phi, radius;
     FL(6);
-    float a = (2.0f * inx) - 1.0f;
-    float b = (2.0f * iny) - 1.0f;
+    float a = cln_fma(2.0f, inx, -1.0f);     /* code.cl:152-153, contracted */
+    float b = cln_fma(2.0f, iny, -1.0f);
     if ((a * a) > (b * b)) {
         FL(3);
         radius = 1.0f * a;
@@ -149,7 +161,7 @@ static void concentric(float inx, float iny, float* ox, float* oy) {
     } else {
         FL(4);
         radius = 1.0f * b;
-        phi = PI_2_F - (PI_4_F * (a / b));
+        phi = cln_fma(-PI_4_F, a / b, PI_2_F);   /* code.cl:164: c - a*b contracts to fma(-a, b, c) */
     }
     float s, c;
     cln_sincos(phi, &s, &c);
@@ -166,7 +178,7 @@ static v3 focal_point(const cam_t* c, float col, float row, float focal_length) 
     FL(2);
     float d = -dot3(pip, N);
     float t = -(dot3(r.o, N) + d) / dot3(r.d, N);
-    return add(r.o, scl(t, r.d));
+    return get_point(r.o, t, r.d);
 }
 
 /* code.cl:183-197 */
@@ -179,7 +191,7 @@ static ray_t thin_lens_ray(const cam_t* c, v3 fp, float lens_rad, float cx, floa
     FL(2);
     dx = dx * lens_rad;
     dy = dy * lens_rad;
-    r.o = add(add(c->eye, scl(dx, c->U)), scl(dy, c->V));
+    r.o = fma3(dy, c->V, fma3(dx, c->U, c->eye));   /* code.cl:190, both sums contracted */
     r.d = norm3(sub(fp, r.o));
     return r;
 }
@@ -264,7 +276,7 @@ typedef struct {
 static axis_t axis_setup(float o, float d, float tmin, float lo, float hi, uint32_t n) {
     axis_t a;
     FL(11);
-    float x = o + tmin * d;
+    float x = cln_fma(tmin, d, o);                 /* code.cl:698 */
     float delta = (hi - lo) / (float)n;
     a.slab = cln_f2i((x - lo) / delta);
     if (a.slab < 0) a.slab = 0;
@@ -272,7 +284,7 @@ static axis_t axis_setup(float o, float d, float tmin, float lo, float hi, uint3
     a.dslab = (d >= 0) ? 1 : -1;
     a.limit = (d >= 0) ? (int)n : -1;
     a.dt = delta / cln_fabs(d);
-    float xnext = lo + (float)(a.slab + ((d >= 0) ? 1 : 0)) * delta;
+    float xnext = cln_fma((float)(a.slab + ((d >= 0) ? 1 : 0)), delta, lo);   /* code.cl:706 */
     a.tnext = (xnext - o) / d;
     return a;
 }
@@ -440,10 +452,10 @@ void oracle_a10_bouncePaths(void* pois_, void* rays_, int* seeds, unsigned total
             float sy = get_rand(&seeds[id]);
             concentric(sx, sy, &sx, &sy);
             FL(5);
-            float sz = cln_sqrt(cln_max(0.0f, 1.0f - sx * sx - sy * sy));
+            float sz = cln_sqrt(cln_max(0.0f, cln_fma(-sy, sy, cln_fma(-sx, sx, 1.0f))));   /* code.cl:568 */
             ray_t r;
             r.o = ld3(poi->p);
-            r.d = norm3(add(add(scl(sx, T), scl(sy, B)), scl(sz, N)));
+            r.d = norm3(fma3(sz, N, fma3(sx, T, scl(sy, B))));                               /* code.cl:574 */
             r.mint = 0.0f;
             r.maxt = PT_INF;
             st_ray(&rays[id], r);
@@ -474,7 +486,7 @@ void oracle_a10_lightRender(void* pois_, void* rays_, void* acu_, const float* l
         if (num == 0.0f) continue;
         FL(1);
         float t = num / den;
-        v3 p = add(ray.o, scl(t, ray.d));
+        v3 p = get_point(ray.o, t, ray.d);
         if (len3(sub(p, lpos)) > radius) continue;
         if (t >= ray.maxt) continue;
         rays[id].mint = PT_INF;
@@ -500,14 +512,14 @@ void oracle_a10_initShadowTrace(void* shadow_, void* pois_, unsigned total, cons
             shadow[id].maxt = PT_INF;
             continue;
         }
-        v3 p = add(ld3(poi->p), scl(0.001f, ld3(poi->n)));
+        v3 p = fma3(0.001f, ld3(poi->n), ld3(poi->p));                /* code.cl:659: p += normal * 0.001f */
         float x = get_rand(&seeds[id]);
         float y = get_rand(&seeds[id]);
         concentric(x, y, &x, &y);
         FL(2);
         x = x * radius;
         y = y * radius;
-        v3 lpos = add(lpos0, add(scl(x, T), scl(y, B)));
+        v3 lpos = add(lpos0, fma3(x, T, scl(y, B)));                 /* code.cl:666: light_pos += x*T + y*B */
         ray_t r;
         v3 to = sub(lpos, p);
         r.o = p;
@@ -532,7 +544,7 @@ static void closest_kernel(unsigned total, pto_poi* pois, pto_ray* rays, const f
         champ_t ch = grid_trace(ray, bh, &bound, n_slabs, cell_off, prims, kind, 0);
         if (ch.idx == UINT_MAX) continue;
         rays[id].maxt = ch.t;
-        v3 p = add(ray.o, scl(ch.t, ray.d));
+        v3 p = get_point(ray.o, ch.t, ray.d);
         v3 nrm;
         if (kind == PRIM_SPHERE) {
             nrm = norm3(sub(p, ld3(prims + 4u * (size_t)ch.idx)));       /* code.cl:794-797 */
@@ -540,7 +552,7 @@ static void closest_kernel(unsigned total, pto_poi* pois, pto_ray* rays, const f
             const float* nn = normals + 12u * (size_t)ch.idx;             /* code.cl:405-411, 927-931 */
             FL(2);
             float w = 1.0f - ch.beta - ch.gamma;
-            nrm = norm3(add(add(scl(w, ld3(nn)), scl(ch.beta, ld3(nn + 4))), scl(ch.gamma, ld3(nn + 8))));
+            nrm = norm3(fma3(ch.gamma, ld3(nn + 8), fma3(w, ld3(nn), scl(ch.beta, ld3(nn + 4)))));   /* code.cl:410 */
         }
         /* trace kernels write p, normal, matId -- never atte (SURVEY 8a hazard 2) */
         st3(pois[id].p, p);
@@ -652,6 +664,36 @@ void oracle_a10_copyToPixel(void* pixel_, void* acu_, float m, unsigned pixels, 
 
 float oracle_bi_sin(float x) { return cln_sin(x); }
 float oracle_bi_cos(float x) { return cln_cos(x); }
+void oracle_set_hw_tables(const signed char* rsq_delta, const signed char* sqrt_delta) { cln_hw_tables((const int8_t*)rsq_delta, (const int8_t*)sqrt_delta); }
+
+/* element-wise probes of the CPU model, for tests/test_ref_gpu.py (op names as in oracle/probe/builtins.cl) */
+void oracle_bi_eval(const char* op, const float* a, const float* b, const float* c, float* o, size_t n) {
+#define EACH for (size_t i = 0; i < n; ++i)
+    if (!strcmp(op, "sqrt")) EACH o[i] = cln_sqrt(a[i]);
+    else if (!strcmp(op, "sin")) EACH o[i] = cln_sin(a[i]);
+    else if (!strcmp(op, "cos")) EACH o[i] = cln_cos(a[i]);
+    else if (!strcmp(op, "fabs")) EACH o[i] = cln_fabs(a[i]);
+    else if (!strcmp(op, "f2i")) EACH { int32_t v = cln_f2i(a[i]); memcpy(&o[i], &v, 4); }
+    else if (!strcmp(op, "f2u")) EACH { uint32_t v = cln_f2u(a[i]); memcpy(&o[i], &v, 4); }
+    else if (!strcmp(op, "div")) EACH o[i] = a[i] / b[i];
+    else if (!strcmp(op, "fmin")) EACH o[i] = cln_fmin(a[i], b[i]);
+    else if (!strcmp(op, "fmax")) EACH o[i] = cln_fmax(a[i], b[i]);
+    else if (!strcmp(op, "min")) EACH o[i] = cln_min(a[i], b[i]);
+    else if (!strcmp(op, "max")) EACH o[i] = cln_max(a[i], b[i]);
+    else if (!strcmp(op, "mad")) EACH o[i] = cln_mad(a[i], b[i], c[i]);
+    else if (!strcmp(op, "clamp")) EACH o[i] = cln_clamp(a[i], b[i], c[i]);
+    else if (!strcmp(op, "muladd")) EACH {
+        o[4 * i] = cln_fma(a[i], b[i], c[i]); o[4 * i + 1] = cln_fma(a[i], b[i], -c[i]);
+        o[4 * i + 2] = cln_fma(-a[i], b[i], c[i]); o[4 * i + 3] = cln_fma(a[i], b[i], c[i] * a[i]);
+    }
+    else if (!strcmp(op, "dot")) EACH o[i] = cln_dot3(a[3 * i], a[3 * i + 1], a[3 * i + 2], b[3 * i], b[3 * i + 1], b[3 * i + 2]);
+    else if (!strcmp(op, "cross")) EACH cln_cross3(a + 3 * i, b + 3 * i, o + 3 * i);
+    else if (!strcmp(op, "length")) EACH o[i] = cln_length3(a[3 * i], a[3 * i + 1], a[3 * i + 2]);
+    else if (!strcmp(op, "distance")) EACH o[i] = cln_length3(a[3 * i] - b[3 * i], a[3 * i + 1] - b[3 * i + 1], a[3 * i + 2] - b[3 * i + 2]);
+    else if (!strcmp(op, "normalize")) EACH cln_normalize3(a + 3 * i, o + 3 * i);
+    else { fprintf(stderr, "oracle_bi_eval: unknown op %s\n", op); abort(); }
+#undef EACH
+}
 
 /* ========================================================================== *
  *  Single-frame kernels of the earlier assignments (BASELINE configs 1-3).   *
@@ -674,7 +716,7 @@ void oracle_a01_raytrace(void* pixels_, const float* cam, size_t gx, size_t gy) 
             if (!((float)col < cols) || !((float)row < rows)) continue;
             float sx = (-0.5f + ((float)(uint32_t)col + 0.5f) / cols) * width;
             float sy = (0.5f - ((float)(uint32_t)row + 0.5f) / rows) * height;
-            v3 cop = add(add(scl(sx, U), scl(sy, Vv)), scl(-1.0f, W));
+            v3 cop = add(fma3(sx, U, scl(sy, Vv)), scl(-1.0f, W));   /* A01 code.cl:54-56 */
             v3 o = eye;
             v3 d = norm3(sub(cop, o));
             const v3 sc = V(0.0f, 0.0f, 1.0f);
@@ -682,8 +724,8 @@ void oracle_a01_raytrace(void* pixels_, const float* cam, size_t gx, size_t gy) 
             v3 omc = sub(o, sc);
             float a = dot3(d, d);
             float b = 2.0f * dot3(omc, d);
-            float c = dot3(omc, omc) - sr * sr;
-            float dis = b * b - 4.0f * a * c;
+            float c = cln_fma(-sr, sr, dot3(omc, omc));             /* A01 code.cl:68 */
+            float dis = cln_fma(b, b, -((4.0f * a) * c));           /* A01 code.cl:69 */
             int v = 0;
             float t = PT_INF;
             if (!(dis < 0.0f)) {
@@ -745,7 +787,7 @@ static int inter_triangle_open(const ray_t* r, const float* tp, int gamma_le_1, 
 static v3 interp_normal(const float* normals, uint32_t i, float beta, float gamma) {
     const float* nn = normals + 12u * (size_t)i;
     float w = 1.0f - beta - gamma;
-    return norm3(add(add(scl(w, ld3(nn)), scl(beta, ld3(nn + 4))), scl(gamma, ld3(nn + 8))));
+    return norm3(fma3(gamma, ld3(nn + 8), fma3(w, ld3(nn), scl(beta, ld3(nn + 4)))));   /* A04 code.cl:193, A07 code.cl:300 */
 }
 
 /* A04 code.cl:262-315: every pixel against every triangle */
@@ -880,7 +922,7 @@ void oracle_a07_molTrace(void* pixels_, const float* cam16, void* rays_, unsigne
             if (champ_i == UINT_MAX) continue;
             rays[pix].maxt = champ_t;
             const float* a = atoms + 4u * (size_t)champ_i;
-            v3 ip = add(ray.o, scl(champ_t, ray.d));
+            v3 ip = get_point(ray.o, champ_t, ray.d);
             v3 c = {a[0], a[1], a[2]};
             float shade = cln_clamp(dot3(cam.W, norm3(sub(ip, c))), 0.0f, 1.0f);
             float k = shade * 127.0f;

@@ -64,6 +64,10 @@ void oracle_a07_molTrace(void* pixels, const float* cam, void* rays, unsigned s_
 /* built-in probes (tests compare them with the functions the compiled reference called) */
 float oracle_bi_sin(float x);
 float oracle_bi_cos(float x);
+/* the measured v_rsq_f32 / v_sqrt_f32 tables (oracle/hw_tables.bin.z, int8[2^24] each); must be set before the first kernel runs */
+void oracle_set_hw_tables(const signed char* rsq_delta, const signed char* sqrt_delta);
+/* the CPU model of one built-in over arrays; op = the kernel name of oracle/probe/builtins.cl without its "b_" */
+void oracle_bi_eval(const char* op, const float* a, const float* b, const float* c, float* o, size_t n);
 
 /* fp32 operation counter for the roofline's algorithmic-flop constant:
  * + - * / sqrt count 1 each, sin/cos count 1 each; compares, min/max, selects,

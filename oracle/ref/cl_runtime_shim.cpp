@@ -13,11 +13,13 @@
 //      2-D initTrace launch -- that ORDER is the oracle's definition of the
 //      reference's seeds[col] race (A10 code.cl:429 vs :469-470).
 //
-// The kernel bodies are the reference's, unmodified.  The built-ins are ours:
-// OpenCL leaves their bits to the implementation, so this file (through
-// ../cl_numerics.h) is where the numerics contract is pinned.  DESIGN.md
-// "Oracle" states this openly: parity is pinned to the compiled reference
-// kernels *given* these built-in definitions.
+// The kernel bodies are the reference's, unmodified, compiled with the OpenCL
+// front end's default contraction (-ffp-contract=on, -mfma: every llvm.fmuladd
+// becomes one fused operation, as on gfx950).  The built-ins are the CPU MODEL
+// (../cl_numerics.h) of AMD's OpenCL C library on gfx950.  This x86 build is the
+// container-side twin of the real pin, oracle/_ref/a10_gfx950.hsaco (the same
+// text compiled by AMD's OpenCL toolchain and run on the MI355X, oracle/ref_gpu.py):
+// tests/test_ref_gpu.py holds the two equal, bit for bit, on every fixture.
 //
 // Nothing in here is shipped or timed; the .so lands in oracle/_ref/.
 
@@ -83,35 +85,22 @@ float3 cl_fabs3(float3 v) {
     r.z = cln_fabs(v.z);
     return r;
 }
-float cl_dot(float3 a, float3 b) {
-    float s = a.x * b.x;
-    s = s + a.y * b.y;
-    s = s + a.z * b.z;
-    return s;
-}
+float cl_dot(float3 a, float3 b) { return cln_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 float3 cl_cross(float3 a, float3 b) {
-    float3 r;
-    r.x = a.y * b.z - a.z * b.y;
-    r.y = a.z * b.x - a.x * b.z;
-    r.z = a.x * b.y - a.y * b.x;
-    return r;
+    const float A[3] = {a.x, a.y, a.z}, B[3] = {b.x, b.y, b.z};
+    float r[3];
+    cln_cross3(A, B, r);
+    return (float3){r[0], r[1], r[2]};
 }
-float cl_length(float3 a) { return cln_sqrt(cl_dot(a, a)); }
-float cl_distance(float3 a, float3 b) {
-    float3 d;
-    d.x = a.x - b.x;
-    d.y = a.y - b.y;
-    d.z = a.z - b.z;
-    return cl_length(d);
-}
+float cl_length(float3 a) { return cln_length3(a.x, a.y, a.z); }
+float cl_distance(float3 a, float3 b) { return cln_length3(a.x - b.x, a.y - b.y, a.z - b.z); }
 float3 cl_normalize(float3 a) {
-    float inv = 1.0f / cln_sqrt(cl_dot(a, a));
-    float3 r;
-    r.x = a.x * inv;
-    r.y = a.y * inv;
-    r.z = a.z * inv;
-    return r;
+    const float A[3] = {a.x, a.y, a.z};
+    float r[3];
+    cln_normalize3(A, r);
+    return (float3){r[0], r[1], r[2]};
 }
+extern "C" void ref_set_hw_tables(const signed char* rsq_delta, const signed char* sqrt_delta) { cln_hw_tables((const int8_t*)rsq_delta, (const int8_t*)sqrt_delta); }
 
 // ---- 3. kernels of the compiled reference + work-item loops ---------------
 struct AABB { float3 pmin; float3 pmax; };
