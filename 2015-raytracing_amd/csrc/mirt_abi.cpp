@@ -414,6 +414,7 @@ int mirt_ctx_destroy(mirt_ctx* ctx) try {
 // ---- device groups: N contexts in one process + the one exchange of the path ---------------------------------------------
 // RCCL is bound at run time (dlopen of librccl.so) the first time a group with more than one device -- or a forced RCCL gather --
 // is created: a single-GPU host never loads it.
+extern "C++" {
 namespace {
 struct Rccl {
     void* lib = nullptr;
@@ -444,6 +445,7 @@ Rccl& rccl() {
 }
 constexpr int kNcclUint8 = 1;   // ncclUint8 / ncclChar family: rccl.h ncclDataType_t { ncclInt8 = 0, ncclUint8 = 1, ... }
 }  // namespace
+}  // extern "C++"
 
 struct mirt_group {
     std::vector<mirt_ctx*> ctxs;
@@ -1169,11 +1171,14 @@ int mirt_zero(mirt_ctx* ctx, mirt_buf* buf) try {
 int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_numerics: unknown context");
     int rc;
-    if ((rc = need(ctx, "mirt_debug_numerics a", a, (uint64_t)n * 4))) return rc;
-    if (b && (rc = need(ctx, "mirt_debug_numerics b", b, (uint64_t)n * 4))) return rc;
-    if ((rc = need(ctx, "mirt_debug_numerics out", out, (uint64_t)n * 4))) return rc;
-    if (op < 0 || op > 13) return fail(ctx, MIRT_E_ARG, "mirt_debug_numerics: op %d outside 0..13", op);
-    if (!b && (op == 0 || (op >= 6 && op <= 12))) return fail(ctx, MIRT_E_ARG, "mirt_debug_numerics: op %d needs two inputs", op);
+    if (!((op >= 0 && op <= 14) || (op >= 20 && op <= 27))) return fail(ctx, MIRT_E_ARG, "mirt_debug_numerics: op %d outside 0..14, 20..27", op);
+    const bool vec = op >= 20 && op != 25;
+    const uint64_t in_w = vec ? 3 : 1, out_w = (op == 21 || op == 24) ? 3 : op == 27 ? 4 : 1;
+    const bool two = op == 0 || (op >= 6 && op <= 12) || op == 20 || op == 21 || op == 23 || op == 25;
+    if ((rc = need(ctx, "mirt_debug_numerics a", a, (uint64_t)n * 4 * in_w))) return rc;
+    if (two && !b) return fail(ctx, MIRT_E_ARG, "mirt_debug_numerics: op %d needs two inputs", op);
+    if (b && (rc = need(ctx, "mirt_debug_numerics b", b, (uint64_t)n * 4 * (two ? in_w : 1)))) return rc;
+    if ((rc = need(ctx, "mirt_debug_numerics out", out, (uint64_t)n * 4 * out_w))) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pt::launch_numerics(ctx->stream, op, a->ptr, b ? b->ptr : nullptr, out->ptr, n);
     HIPCHK(ctx, hipGetLastError());

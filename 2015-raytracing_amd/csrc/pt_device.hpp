@@ -6,13 +6,14 @@
 //     for the fourteen `__kernel`s of A10 code.cl behind the WebCL-shaped API;
 //   * the fused per-ray pass kernel (pt_kernels_fused.hip).
 // "A10 code.cl:NNN" cites the reference lines whose behaviour a block reproduces.
-// Evaluation order is part of the contract (pt_numerics.hpp): every expression is
-// spelled in the order OpenCL C evaluates the reference's, never contracted.
+// Evaluation order and fusion are part of the contract (pt_numerics.hpp): every expression is spelled in the order OpenCL C
+// evaluates the reference's, with fma3 / cl_fma exactly where the OpenCL front end contracts the reference's text.
 #pragma once
 #include "pt_numerics.hpp"
 
 namespace pt {
 
+#define PT_INF_ (__builtin_inff())
 struct f3 { float x, y, z; };
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -21,24 +22,40 @@ PT_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 PT_DEV f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV f3 scl3(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
 PT_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
-PT_DEV float dot3(f3 a, f3 b) {
-    float s = a.x * b.x;
-    s = s + a.y * b.y;
-    s = s + a.z * b.z;
-    return s;
-}
+// s*a + c, one rounding per component: the sites the OpenCL front end contracts (A10 code.cl:87, 111, 190, 410, 574, 659, 666)
+PT_DEV f3 fma3(float s, f3 a, f3 c) { return mk3(cl_fma(s, a.x, c.x), cl_fma(s, a.y, c.y), cl_fma(s, a.z, c.z)); }
+// dot, cross, length, normalize: AMD's OpenCL library definitions (opencl.bc), see pt_numerics.hpp
+PT_DEV float dot3(f3 a, f3 b) { return cl_fma(a.z, b.z, cl_fma(a.y, b.y, a.x * b.x)); }
 PT_DEV f3 cross3(f3 a, f3 b) {
-    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return mk3(cl_fma(a.y, b.z, -(a.z * b.y)), cl_fma(a.z, b.x, -(a.x * b.z)), cl_fma(a.x, b.y, -(a.y * b.x)));
 }
-PT_DEV float len3(f3 a) { return cl_sqrt(dot3(a, a)); }
+PT_DEV float len3(f3 a) {
+    const float d = dot3(a, a);
+    if (__builtin_expect(d < 0x1p-126f, 0)) { const f3 b = scl3(0x1p+86f, a); return cl_sqrt_approx(dot3(b, b)) * 0x1p-86f; }
+    if (__builtin_expect(d == PT_INF_, 0)) { const f3 b = scl3(0x1p-66f, a); return cl_sqrt_approx(dot3(b, b)) * 0x1p+66f; }
+    return __builtin_amdgcn_sqrtf(d);
+}
 PT_DEV f3 norm3(f3 a) {
-    float inv = rcp_exact(cl_sqrt(dot3(a, a)));
-    return mk3(a.x * inv, a.y * inv, a.z * inv);
+    float d = dot3(a, a);
+    if (__builtin_expect(!(d >= 0x1p-126f && d < PT_INF_), 0)) {   // the library's corner cases, in its order
+        if (a.x == 0.0f && a.y == 0.0f && a.z == 0.0f) return a;
+        if (d < 0x1p-126f) { a = scl3(0x1p+86f, a); d = dot3(a, a); }
+        else if (d == PT_INF_) {
+            a = scl3(0x1p-66f, a); d = dot3(a, a);
+            if (d == PT_INF_) {
+                a = mk3(__builtin_copysignf(__builtin_isinf(a.x) ? 1.0f : 0.0f, a.x), __builtin_copysignf(__builtin_isinf(a.y) ? 1.0f : 0.0f, a.y),
+                        __builtin_copysignf(__builtin_isinf(a.z) ? 1.0f : 0.0f, a.z));
+                d = dot3(a, a);
+            }
+        }
+        return scl3(cl_rsqrt(d), a);
+    }
+    return scl3(__builtin_amdgcn_rsqf(d), a);
 }
 PT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 PT_DEV f3 ld3(const float4& v) { return mk3(v.x, v.y, v.z); }
 
-#define PT_INF (__builtin_inff())
+#define PT_INF PT_INF_
 #define PT_PI_4 0.785398163397448309616f
 #define PT_PI_2 1.57079632679489661923f
 
@@ -80,13 +97,12 @@ PT_DEV float get_rand(int32_t& seed) { seed = lcg_next(seed); return lcg_float(s
 // ---- camera: A10 code.cl:108-119, 143-197 ------------------------------------------
 PT_DEV void concentric(float inx, float iny, float& ox, float& oy) {
     if (inx == 0.0f && iny == 0.0f) { ox = inx; oy = iny; return; }
-    float a = (2.0f * inx) - 1.0f;
-    float b = (2.0f * iny) - 1.0f;
+    float a = cl_fma(2.0f, inx, -1.0f);        // code.cl:152-153, contracted
+    float b = cl_fma(2.0f, iny, -1.0f);
     const bool top = (a * a) > (b * b);
     float radius = top ? (1.0f * a) : (1.0f * b);
     float q = top ? (b / a) : (a / b);
-    float pq = PT_PI_4 * q;
-    float phi = top ? pq : (PT_PI_2 - pq);
+    float phi = top ? (PT_PI_4 * q) : cl_fma(-PT_PI_4, q, PT_PI_2);   // code.cl:164: c - a*b contracts to fma(-a, b, c)
     float s, c;
     cl_sincos(phi, s, c);
     ox = c * radius;
@@ -96,13 +112,13 @@ PT_DEV void concentric(float inx, float iny, float& ox, float& oy) {
 PT_DEV f3 focal_point(const Cam& c, float col, float row, float focal_length) {
     float sx = (-0.5f + (col + 0.5f) / (float)c.cols) * c.width;
     float sy = (0.5f - (row + 0.5f) / (float)c.rows) * c.height;
-    f3 cop = add3(add3(scl3(sx, c.U), scl3(sy, c.V)), scl3(-1.0f, c.W));
+    f3 cop = add3(fma3(sx, c.U, scl3(sy, c.V)), scl3(-1.0f, c.W));   // code.cl:111-113: fma(sx, U, sy*V), then + (-W) (exact either way)
     f3 d = norm3(cop);
     f3 o = c.eye;
-    f3 pip = add3(c.eye, scl3(-1.0f, scl3(focal_length, c.W)));
+    f3 pip = add3(c.eye, scl3(-1.0f, scl3(focal_length, c.W)));       // code.cl:176: the product by -1 is exact, fused or not
     float pd = -dot3(pip, c.W);
     float t = -(dot3(o, c.W) + pd) / dot3(d, c.W);
-    return add3(o, scl3(t, d));
+    return fma3(t, d, o);                                              // getPoint, code.cl:87
 }
 
 PT_DEV Ray thin_lens_ray(const Cam& c, f3 fp, float lens_rad, float cx, float cy) {
@@ -111,7 +127,7 @@ PT_DEV Ray thin_lens_ray(const Cam& c, f3 fp, float lens_rad, float cx, float cy
     concentric(cx, cy, dx, dy);
     dx = dx * lens_rad;
     dy = dy * lens_rad;
-    r.o = add3(add3(c.eye, scl3(dx, c.U)), scl3(dy, c.V));
+    r.o = fma3(dy, c.V, fma3(dx, c.U, c.eye));                        // code.cl:190
     r.d = norm3(sub3(fp, r.o));
     r.mint = 0.0f;
     r.maxt = PT_INF;
@@ -159,7 +175,7 @@ struct Axis { int slab, dslab, limit; float dt, tnext; };
 
 PT_DEV Axis axis_setup(float o, float d, float tmin, float lo, float hi, uint32_t n) {
     Axis a;
-    float x = o + tmin * d;
+    float x = cl_fma(tmin, d, o);                                      // code.cl:698
     float delta = (hi - lo) / (float)n;
     a.slab = f2i((x - lo) / delta);
     if (a.slab < 0) a.slab = 0;
@@ -168,7 +184,7 @@ PT_DEV Axis axis_setup(float o, float d, float tmin, float lo, float hi, uint32_
     a.dslab = fwd ? 1 : -1;
     a.limit = fwd ? (int)n : -1;
     a.dt = delta / cl_fabs(d);
-    float xnext = lo + (float)(a.slab + (fwd ? 1 : 0)) * delta;
+    float xnext = cl_fma((float)(a.slab + (fwd ? 1 : 0)), delta, lo);  // code.cl:706
     a.tnext = (xnext - o) / d;
     return a;
 }
@@ -186,20 +202,20 @@ PT_DEV bool light_visible(const Ray& ray, f3 lpos, f3 lnor, float radius) {
     float num = dot3(sub3(lpos, ray.o), lnor);
     if (num == 0.0f) return false;
     float t = num / den;
-    f3 p = add3(ray.o, scl3(t, ray.d));
+    f3 p = fma3(t, ray.d, ray.o);
     if (len3(sub3(p, lpos)) > radius) return false;
     return !(t >= ray.maxt);
 }
 
 // code.cl:121-129 + 631-673: offset origin, concentric sample on the disk light, ray to it
 PT_DEV Ray shadow_ray(const Poi& poi, f3 lpos0, f3 T, f3 B, float radius, int32_t& seed) {
-    f3 p = add3(poi.p, scl3(0.001f, poi.n));
+    f3 p = fma3(0.001f, poi.n, poi.p);                                 // code.cl:659
     float x = get_rand(seed);
     float y = get_rand(seed);
     concentric(x, y, x, y);
     x = x * radius;
     y = y * radius;
-    f3 lpos = add3(lpos0, add3(scl3(x, T), scl3(y, B)));
+    f3 lpos = add3(lpos0, fma3(x, T, scl3(y, B)));                     // code.cl:666
     f3 to = sub3(lpos, p);
     Ray r;
     r.o = p;
@@ -238,10 +254,10 @@ PT_DEV Ray bounce_ray(const Poi& poi, int32_t& seed) {
     float sx = get_rand(seed);
     float sy = get_rand(seed);
     concentric(sx, sy, sx, sy);
-    float sz = cl_sqrt(cl_max(0.0f, 1.0f - sx * sx - sy * sy));
+    float sz = cl_sqrt(cl_max(0.0f, cl_fma(-sy, sy, cl_fma(-sx, sx, 1.0f))));   // code.cl:568
     Ray r;
     r.o = poi.p;
-    r.d = norm3(add3(add3(scl3(sx, T), scl3(sy, B)), scl3(sz, N)));
+    r.d = norm3(fma3(sz, N, fma3(sx, T, scl3(sy, B))));                          // code.cl:574
     r.mint = 0.0f;
     r.maxt = PT_INF;
     return r;

@@ -28,7 +28,7 @@ PT_DEV Ray load_ray48(const RayAoS* p) {
 PT_DEV Ray pinhole_ray(const Cam& c, float col, float row) {
     float sx = (-0.5f + (col + 0.5f) / (float)c.cols) * c.width;
     float sy = (0.5f - (row + 0.5f) / (float)c.rows) * c.height;
-    f3 cop = add3(add3(scl3(sx, c.U), scl3(sy, c.V)), scl3(-1.0f, c.W));
+    f3 cop = add3(fma3(sx, c.U, scl3(sy, c.V)), scl3(-1.0f, c.W));
     Ray r;
     r.d = norm3(cop);
     r.o = c.eye;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_a01_raytrace(uchar4* pixels, F16 cam, u
     f3 eye = ld3(cam.v), U = ld3(cam.v + 3), V = ld3(cam.v + 6), W = ld3(cam.v + 9);
     float sx = (-0.5f + ((float)col + 0.5f) / cols) * cam.v[12];
     float sy = (0.5f - ((float)row + 0.5f) / rows) * cam.v[13];
-    f3 cop = add3(add3(scl3(sx, U), scl3(sy, V)), scl3(-1.0f, W));
+    f3 cop = add3(fma3(sx, U, scl3(sy, V)), scl3(-1.0f, W));
     f3 o = eye;
     f3 d = norm3(sub3(cop, o));
     const f3 sc = mk3(0.0f, 0.0f, 1.0f);
@@ -60,8 +60,8 @@ __global__ void __launch_bounds__(256) k_a01_raytrace(uchar4* pixels, F16 cam, u
     f3 omc = sub3(o, sc);
     float a = dot3(d, d);
     float b = 2.0f * dot3(omc, d);
-    float c = dot3(omc, omc) - sr * sr;
-    float dis = b * b - 4.0f * a * c;
+    float c = cl_fma(-sr, sr, dot3(omc, omc));              // A01 code.cl:68, contracted
+    float dis = cl_fma(b, b, -((4.0f * a) * c));            // A01 code.cl:69: the LEFT product fuses
     bool v = false;
     float t = PT_INF;
     if (!(dis < 0.0f)) {
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) k_frame_initTrace(uchar4* pixels, F16 cam
 PT_DEV f3 interp_normal(const float4* normals, uint32_t i, float beta, float gamma) {
     const float4* nn = normals + 3u * (size_t)i;
     float w = 1.0f - beta - gamma;
-    return norm3(add3(add3(scl3(w, ld3(nn[0])), scl3(beta, ld3(nn[1]))), scl3(gamma, ld3(nn[2]))));
+    return norm3(fma3(gamma, ld3(nn[2]), fma3(w, ld3(nn[0]), scl3(beta, ld3(nn[1])))));
 }
 
 // ---- Assign04 meshTrace: every pixel against every triangle, wave-uniform loop --------------------
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_a07_molTrace(uchar4* pixels, F16 cam16,
     }
     if (champ_i == UINT32_MAX) return;
     rays[pix].maxt = champ_t;
-    const f3 ip = add3(ray.o, scl3(champ_t, ray.d));
+    const f3 ip = fma3(champ_t, ray.d, ray.o);
     const float shade = cl_clamp(dot3(cam.W, norm3(sub3(ip, ld3(atoms[champ_i])))), 0.0f, 1.0f);   // code.cl:455-457
     const float k = shade * 127.0f;                                                                // code.cl:463-469
     pixels[pix] = make_uchar4(f2u8((float)((hx % 2) + 1) * k), f2u8((float)((hy % 2) + 1) * k), f2u8((float)((hz % 2) + 1) * k), 255);

@@ -104,14 +104,14 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
         }
         if (ch.idx == UINT32_MAX) continue;
         ray.maxt = ch.t;
-        poi.p = add3(ray.o, scl3(ch.t, ray.d));
+        poi.p = fma3(ch.t, ray.d, ray.o);   // getPoint, code.cl:87
         if (S.kind == KIND_SPHERES) {
             poi.n = norm3(sub3(poi.p, ld3(((const float4*)S.prims)[ch.idx])));
             poi.matId = (int32_t)((const uint32_t*)S.matid)[ch.idx];
         } else {
             const float4* nn = (const float4*)S.normals + 3u * (size_t)ch.idx;
             float w = 1.0f - ch.beta - ch.gamma;  // code.cl:409-411
-            poi.n = norm3(add3(add3(scl3(w, ld3(nn[0])), scl3(ch.beta, ld3(nn[1]))), scl3(ch.gamma, ld3(nn[2]))));
+            poi.n = norm3(fma3(ch.gamma, ld3(nn[2]), fma3(w, ld3(nn[0]), scl3(ch.beta, ld3(nn[1])))));
             poi.matId = (int32_t)(S.matid ? ((const uint32_t*)S.matid)[ch.idx] : S.mesh_matid);
         }
 #if PT_PARK_LDS && PT_PARK_PN

@@ -238,14 +238,14 @@ __global__ void __launch_bounds__(256) k_closest(uint32_t total, PoiAoS* pois, R
     if (ch.idx == UINT32_MAX) return;
     rays[id].maxt = ch.t;
     // p, normal, matId -- never atte (SURVEY 8a hazard 2); on a miss the previous vertex stays live (hazard 3)
-    f3 p = add3(ray.o, scl3(ch.t, ray.d));
+    f3 p = fma3(ch.t, ray.d, ray.o);   // getPoint, code.cl:87
     f3 nrm;
     if (KIND == SPHERES) {
         nrm = norm3(sub3(p, ld3(prims[ch.idx])));
     } else {
         const float4* nn = normals + 3u * (size_t)ch.idx;
         float w = 1.0f - ch.beta - ch.gamma;                         // code.cl:409-411
-        nrm = norm3(add3(add3(scl3(w, ld3(nn[0])), scl3(ch.beta, ld3(nn[1]))), scl3(ch.gamma, ld3(nn[2]))));
+        nrm = norm3(fma3(ch.gamma, ld3(nn[2]), fma3(w, ld3(nn[0]), scl3(ch.beta, ld3(nn[1])))));
     }
     PoiAoS* pp = &pois[id];
     float4* q = reinterpret_cast<float4*>(pp);
@@ -385,7 +385,8 @@ __global__ void __launch_bounds__(256) k_seedFill(int32_t* seeds, uint64_t first
 __global__ void __launch_bounds__(256) k_numerics(int op, const float* a, const float* b, float* out, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f, t;
+    const bool vec = op >= 20 && op != 25;
+    float x = vec ? 0.0f : a[i], y = (b && !vec) ? b[i] : 0.0f, r = 0.0f, t;
     switch (op) {
         case 0: r = x / y; break;
         case 1: r = cl_sqrt(x); break;
@@ -401,6 +402,20 @@ __global__ void __launch_bounds__(256) k_numerics(int op, const float* a, const 
         case 11: concentric(x, y, r, t); break;
         case 12: concentric(x, y, t, r); break;
         case 13: r = __int_as_float(f2i(x)); break;
+        case 14: r = __uint_as_float(f2u(x)); break;
+        case 25: r = cl_clamp(x, 0.0f, y); break;
+        // float3 arguments: three consecutive floats per element
+        case 20: r = dot3(ld3(a + 3 * i), ld3(b + 3 * i)); break;
+        case 22: r = len3(ld3(a + 3 * i)); break;
+        case 23: r = len3(sub3(ld3(a + 3 * i), ld3(b + 3 * i))); break;                    // distance
+        case 26: r = cl_mad(a[3 * i], a[3 * i + 1], a[3 * i + 2]); break;
+        case 21: { f3 v = cross3(ld3(a + 3 * i), ld3(b + 3 * i)); out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z; return; }
+        case 24: { f3 v = norm3(ld3(a + 3 * i)); out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z; return; }
+        case 27: {   // the four contraction shapes of the OpenCL front end: a*b+c, a*b-c, c-a*b, a*b+c*a
+            const float p = a[3 * i], q = a[3 * i + 1], c = a[3 * i + 2];
+            out[4 * i] = cl_fma(p, q, c); out[4 * i + 1] = cl_fma(p, q, -c); out[4 * i + 2] = cl_fma(-p, q, c); out[4 * i + 3] = cl_fma(p, q, c * p);
+            return;
+        }
         default: break;
     }
     out[i] = r;

@@ -1,17 +1,19 @@
 // pt_numerics.hpp -- the numerics contract of the path on gfx950 (device side).
 //
-// OpenCL C leaves the bits of its built-in math to the implementation, so the
-// "reference output" of A10 code.cl only exists once those are pinned.  The pin
-// (DESIGN.md "Numerics contract") is:
-//   + - *      IEEE binary32, RNE, never contracted  (-ffp-contract=off; every kernel TU)
-//   / , sqrt   correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt:
-//              v_div_scale/v_div_fmas/v_div_fixup and the refined v_sqrt sequence)
-//   min / max  OpenCL common-function form  min(x,y) = y<x ? y : x,  max(x,y) = x<y ? y : x
-//   fmin/fmax  IEEE minNum / maxNum (v_min_f32 / v_max_f32 in IEEE mode)
-//   clamp      fmin(fmax(x,lo),hi)
-//   mad        a*b + c, two roundings                     (A10 code.cl:209)
-//   sin / cos  one shared Cody-Waite reduction + Cephes polynomials, fixed order
-// Denormals are kept (gfx9+ default), no fast-math anywhere.
+// OpenCL C leaves the bits of its built-in math to the implementation, so the "reference output" of A10 code.cl only exists
+// once an implementation is named.  The one named (DESIGN.md "Numerics contract") is the one that exists for this hardware:
+// AMD's own OpenCL C toolchain -- clang in OpenCL mode + the ROCm OpenCL built-in library (opencl.bc / ocml.bc), options
+// -cl-std=CL1.2 -O3 -cl-fp32-correctly-rounded-divide-sqrt.  The reference's code.cl compiled that way
+// (oracle/_ref/a10_gfx950.hsaco, run on the MI355X by oracle/ref_gpu.py) is what these kernels equal bit for bit:
+//   + - *      IEEE binary32, RNE, denormals kept
+//   a*b+c      fused EXACTLY where the OpenCL front end contracts (a product feeding a sum inside one expression; the left
+//              product when both operands are products): written as explicit fmaf here, every TU builds with -ffp-contract=off
+//   / , sqrt() correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt == -cl-fp32-correctly-rounded-divide-sqrt)
+//   dot        fma(a.z,b.z, fma(a.y,b.y, a.x*b.x));  cross.x = fma(a.y,b.z, -(a.z*b.y)) ...     (opencl.bc)
+//   normalize  v * v_rsq_f32(dot(v,v)) with the library's rescaling below 2^-126 / at inf; length = v_sqrt_f32(dot) likewise
+//   min max fmin fmax   v_min_f32 / v_max_f32 (llvm.minnum / maxnum);  clamp = v_med3_f32;  mad = fma
+//   sin / cos  ocml's __ocml_sin_f32 / __ocml_cos_f32 (restated below for |x| < 2^17, the library itself beyond)
+// No fast-math anywhere.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,11 +30,24 @@ namespace pt {
 
 #define PT_DEV __device__ __forceinline__
 
-PT_DEV float cl_min(float x, float y) { return (y < x) ? y : x; }
-PT_DEV float cl_max(float x, float y) { return (x < y) ? y : x; }
+PT_DEV float cl_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_DEV float cl_min(float x, float y) { return __builtin_fminf(x, y); }    // v_min_f32: a NaN loses, -0 < +0
+PT_DEV float cl_max(float x, float y) { return __builtin_fmaxf(x, y); }
 PT_DEV float cl_fmin(float x, float y) { return __builtin_fminf(x, y); }
 PT_DEV float cl_fmax(float x, float y) { return __builtin_fmaxf(x, y); }
-PT_DEV float cl_clamp(float x, float lo, float hi) { return cl_fmin(cl_fmax(x, lo), hi); }
+PT_DEV float cl_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }   // v_med3_f32 (ockl median3)
+// ocml rsqrt (normalize): v_rsq_f32, pre-scaled by 2^24 below 2^-126
+PT_DEV float cl_rsqrt(float x) {
+    const bool tiny = x < 0x1p-126f;
+    const float r = __builtin_amdgcn_rsqf(tiny ? x * 16777216.0f : x);
+    return tiny ? r * 4096.0f : r;
+}
+// llvm.sqrt !fpmath 3.0 as the gfx950 back end lowers it inside length(): v_sqrt_f32, pre-scaled by 2^32 below 2^-126
+PT_DEV float cl_sqrt_approx(float x) {
+    const bool tiny = x < 0x1p-126f;
+    const float r = __builtin_amdgcn_sqrtf(tiny ? __builtin_ldexpf(x, 32) : x);
+    return tiny ? __builtin_ldexpf(r, -16) : r;
+}
 PT_DEV float cl_fabs(float x) { return __builtin_fabsf(x); }
 // Correctly rounded sqrt.  hipcc expands __builtin_sqrtf into: scale denormal inputs up (3 ops), v_sqrt_f32 (1 ulp), try the two
 // neighbours s -+ 1 ulp against the residual (8 ops), scale back (2), patch 0 / inf by class (2).  The scaling exists because the
@@ -62,7 +77,7 @@ PT_DEV float cl_sqrt(float x) {
     return __builtin_sqrtf(x);
 #endif
 }
-PT_DEV float cl_mad(float a, float b, float c) { return a * b + c; }
+PT_DEV float cl_mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // float -> int the way v_cvt_i32_f32 does it (truncate, saturate, NaN -> 0), spelled
 // out so the compiler cannot treat an out-of-range input as poison.
@@ -119,47 +134,31 @@ PT_DEV float rcp_exact(float x, bool dont_care = false) {
 #endif
 }
 
-// sin and cos of one angle.  k = rint(x*2/pi) by the 1.5*2^23 trick; r = x - k*pi/2 in
-// three exact-product steps; Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4].
-// <= 1.5 ulp on [-pi/4, 3pi/4], the only range concentric_distort produces.
+// sin and cos of one angle: ocml's __ocmlpriv_trigredsmall_f32 (gfx9+ branch: n = rint(|x| * 2/pi), three fused subtractions of
+// n * pi/2) and __ocmlpriv_sincosred_f32 (fused minimax polynomials), one shared reduction.  |x| >= 2^17, inf and NaN take the
+// library's own functions (Payne-Hanek reduction there): rare lanes only.
+extern "C" __device__ float __ocml_sin_f32(float);
+extern "C" __device__ float __ocml_cos_f32(float);
 PT_DEV void cl_sincos(float x, float& sn, float& cs) {
-    const float two_over_pi = 0.63661977236758134308f;
-    const float magic = 12582912.0f;
-    const float pio2_hi = 1.5703125f;
-    const float pio2_md = 4.837512969970703125e-4f;
-    const float pio2_lo = 7.54978995489188216e-8f;
-
-    float kf = x * two_over_pi + magic;
-    kf = kf - magic;
-    int32_t q = (kf == kf) ? (int32_t)kf : 0;
-
-    float r = x - kf * pio2_hi;
-    r = r - kf * pio2_md;
-    r = r - kf * pio2_lo;
-    float r2 = r * r;
-
-    float sp = -1.9515295891e-4f * r2;
-    sp = sp + 8.3321608736e-3f;
-    sp = sp * r2;
-    sp = sp - 1.6666654611e-1f;
-    sp = sp * r2;
-    sp = sp * r;
-    float s = sp + r;
-
-    float cp = 2.443315711809948e-5f * r2;
-    cp = cp - 1.388731625493765e-3f;
-    cp = cp * r2;
-    cp = cp + 4.166664568298827e-2f;
-    cp = cp * r2;
-    cp = cp * r2;
-    float c = cp - 0.5f * r2;
-    c = c + 1.0f;
-
-    const bool swap = (q & 1) != 0;
-    float a = swap ? c : s;   // |sin|
-    float b = swap ? s : c;   // |cos|
-    sn = (q & 2) ? -a : a;
-    cs = ((q + 1) & 2) ? -b : b;
+    const float ax = __builtin_fabsf(x);
+    const float n = __builtin_rintf(ax * 0x1.45f306p-1f);
+    float r = __builtin_fmaf(n, -0x1.921fb4p+0f, ax);
+    r = __builtin_fmaf(n, -0x1.4442dp-24f, r);
+    r = __builtin_fmaf(n, -0x1.846988p-48f, r);
+    const int q = (int)n & 3;
+    const float s2 = r * r;
+    float sp = __builtin_fmaf(s2, -0x1.983304p-13f, 0x1.110388p-7f);
+    sp = __builtin_fmaf(s2, sp, -0x1.55553ap-3f);
+    const float s = __builtin_fmaf(r, s2 * sp, r);
+    float cp = __builtin_fmaf(s2, 0x1.aea668p-16f, -0x1.6c9e76p-10f);
+    cp = __builtin_fmaf(s2, cp, 0x1.5557eep-5f);
+    cp = __builtin_fmaf(s2, cp, -0x1.000008p-1f);
+    const float c = __builtin_fmaf(s2, cp, 1.0f);
+    const bool odd = (q & 1) != 0;
+    const uint32_t flip = q > 1 ? 0x80000000u : 0u;
+    sn = __uint_as_float(__float_as_uint(odd ? c : s) ^ flip ^ (__float_as_uint(x) & 0x80000000u));
+    cs = __uint_as_float(__float_as_uint(odd ? -s : c) ^ flip);
+    if (__builtin_expect(!(ax < 131072.0f), 0)) { sn = __ocml_sin_f32(x); cs = __ocml_cos_f32(x); }
 }
 
 }  // namespace pt

@@ -162,7 +162,7 @@ template <bool FAST>
 PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint32_t n, bool& defer) {
     if (!FAST) return axis_setup(o, d, tmin, lo, hi, n);
     Axis a;
-    const float x = o + tmin * d;
+    const float x = cl_fma(tmin, d, o);                    // code.cl:698
     const float fn = (float)n, span = hi - lo;
     const float delta = div_exact3(span, fn, rcp_refined(fn));
     const float num0 = x - lo;
@@ -174,7 +174,7 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     a.limit = fwd ? (int)n : -1;
     const float rd = rcp_refined(d);
     a.dt = div_exact3(delta, cl_fabs(d), cl_fabs(rd));   // rcp_refined is odd in d: every step is sign-symmetric under RNE
-    const float xnext = lo + (float)(a.slab + (fwd ? 1 : 0)) * delta;
+    const float xnext = cl_fma((float)(a.slab + (fwd ? 1 : 0)), delta, lo);   // code.cl:706
     const float num1 = xnext - o;
     a.tnext = div_exact3(num1, d, rd);
     defer = defer || !(num_window(span) && num_window(num0) && den_window(delta) && num_window(num1));

@@ -273,13 +273,16 @@ class Context:
         return n, miss.value.decode()
 
     def debug_numerics(self, op, a, b=None):
+        """op 0..14: one float per element; 20..27 except 25: float3 arguments as three consecutive floats (include/mirt.h)"""
         a = np.ascontiguousarray(a, np.float32)
-        n = a.size
+        vec = op >= 20 and op != 25
+        n = a.size // 3 if vec else a.size
+        out_w = 3 if op in (21, 24) else 4 if op == 27 else 1
         da = self.buffer_from(a, MEM_READ_WRITE)
         db = self.buffer_from(np.ascontiguousarray(b, np.float32), MEM_READ_WRITE) if b is not None else None
-        do = self.buffer(max(4 * n, 16))
+        do = self.buffer(max(4 * n * out_w, 16))
         self._chk(lib().mirt_debug_numerics(self.h, op, da.h, db.h if db else None, do.h, n))
-        out = do.read(np.float32, n)
+        out = do.read(np.float32, n * out_w)
         for x in (da, db, do):
             if x:
                 x.release()

@@ -208,9 +208,11 @@ MIRT_API int mirt_grid_gather_spheres(mirt_ctx* ctx, mirt_buf* order, uint32_t t
 MIRT_API int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* in_u32, mirt_buf** out);       /* material ids */
 
 /* ---- diagnostics: evaluate one primitive of the numerics contract element-wise on the device
- * (op: 0 a/b, 1 sqrt, 2 sin, 3 cos, 4 getRand(seed=bits of a), 5 next LCG state, 6 min, 7 max,
- * 8 fmin, 9 fmax, 10 normalize(a,b,1).x, 11/12 concentric_distort(a,b).x/.y, 13 (int)a).
- * Lets a test compare device bits with host bits over millions of inputs. ---------------- */
+ * (op: 0 a/b, 1 sqrt, 2 sin, 3 cos, 4 getRand(seed=bits of a), 5 next LCG state, 6 min, 7 max, 8 fmin, 9 fmax,
+ * 10 normalize(a,b,1).x, 11/12 concentric_distort(a,b).x/.y, 13 (int)a, 14 (uint)a, 25 clamp(a,0,b);
+ * float3 arguments as three consecutive floats per element: 20 dot, 21 cross (3 outputs), 22 length, 23 distance,
+ * 24 normalize (3 outputs), 26 mad(a.x,a.y,a.z), 27 the four contraction shapes a*b+c, a*b-c, c-a*b, a*b+c*a (4 outputs)).
+ * Lets a test compare device bits with AMD's OpenCL library (oracle/probe/builtins.cl) over millions of inputs. ---- */
 MIRT_API int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n);
 
 /* counts mismatches between the shared-reciprocal division forms of pt_numerics.hpp and the compiler's correctly

@@ -42,8 +42,17 @@ def load_fixture(name):
 
 
 def bits(a):
+    """bit patterns of a float32 array, every NaN mapped to one pattern: NaN payloads and signs are outside the numerics contract
+    (x86, where the fixtures are made, and gfx950 propagate them differently; oracle/cl_numerics.h)"""
     a = np.ascontiguousarray(a)
-    return a.view(np.uint32) if a.dtype == np.float32 else a
+    if a.dtype != np.float32:
+        return a
+    u = a.view(np.uint32).copy()
+    u[(u & 0x7FFFFFFF) > 0x7F800000] = 0x7FC00000
+    return u
+
+
+canon = bits
 
 
 def assert_state_equal(tag, got, fx, prefix):

@@ -1,6 +1,7 @@
 """GPU: the numerics contract on gfx950 -- correctly rounded / and sqrt, the shared sin/cos, the
-LCG, min/max forms -- compared bit for bit with the CPU restatement's primitives (oracle/cl_numerics.h
-via liboracle.so probes, numpy for IEEE / and sqrt) over millions of inputs."""
+LCG, min/max forms -- compared bit for bit with the CPU model's primitives (oracle/cl_numerics.h
+via liboracle.so probes, numpy for IEEE / and sqrt) over millions of inputs.  The comparison of every built-in with
+AMD's OpenCL library itself is tests/test_ref_gpu.py."""
 import ctypes as C
 
 import numpy as np
@@ -82,19 +83,22 @@ def test_lcg_matches_reference_known_answers(ctx):
 
 
 def test_min_max_forms(ctx):
+    """min / max / fmin / fmax are all v_min_f32 / v_max_f32 (AMD's OpenCL library: llvm.minnum / maxnum): a NaN loses, -0 < +0."""
     a, b = rnd(1 << 16, 11), rnd(1 << 16, 12)
     a[:100] = np.nan
     b[50:150] = np.nan
     a[200:210], b[200:210] = 0.0, -0.0
+    a[210:220], b[210:220] = -0.0, 0.0
     with np.errstate(all="ignore"):
-        assert np.array_equal(ctx.debug_numerics(6, a, b).view(np.uint32), np.where(b < a, b, a).view(np.uint32))   # min(x,y) = y<x?y:x
-        assert np.array_equal(ctx.debug_numerics(7, a, b).view(np.uint32), np.where(a < b, b, a).view(np.uint32))   # max(x,y) = x<y?y:x
-        fm = ctx.debug_numerics(8, a, b)
-        fM = ctx.debug_numerics(9, a, b)
-    both = ~np.isnan(a) & ~np.isnan(b) & ~((a == 0) & (b == 0))
-    assert np.array_equal(fm[both], np.minimum(a, b)[both]) and np.array_equal(fM[both], np.maximum(a, b)[both])
-    one = np.isnan(a) ^ np.isnan(b)
-    assert not np.isnan(fm[one]).any() and not np.isnan(fM[one]).any()       # a NaN loses
+        want_min, want_max = np.fmin(a, b), np.fmax(a, b)
+    z = (a == 0) & (b == 0)
+    want_min[z] = np.where(np.signbit(a[z]) | np.signbit(b[z]), np.float32(-0.0), np.float32(0.0))
+    want_max[z] = np.where(np.signbit(a[z]) & np.signbit(b[z]), np.float32(-0.0), np.float32(0.0))
+    from conftest import bits
+    for op in (6, 8):
+        assert np.array_equal(bits(ctx.debug_numerics(op, a, b)), bits(want_min)), op
+    for op in (7, 9):
+        assert np.array_equal(bits(ctx.debug_numerics(op, a, b)), bits(want_max)), op
 
 
 def test_concentric_map_matches_cpu_formula(ctx):
