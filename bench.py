@@ -33,28 +33,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-# measured constants (DESIGN.md "Algorithmic work"): oracle/liboracle_count.so on cornell.xml 320x240 rpp 16
-FLOPS_PER_SAMPLE = {5: 6632.7, 8: 9812.3}
+# measured constants (DESIGN.md "Algorithmic work"): `make -C oracle count && python oracle/count_flops.py` -- the CPU oracle with its
+# operation counters on the scene at 320x240 x 16 rays (+ - * / sqrt sin cos = 1, a fused multiply-add = 2); {scene: {bounces: flop/sample}}
+FLOPS_PER_SAMPLE = {"cornell": {5: 6612.3, 8: 9788.3}, "cornell_teapot3": {5: 10905.6, 8: 16342.6}}
+# --scene NAME: tests/golden/<this fixture>.npz carries the scene as the reference host packed it
+SCENE_FIXTURE = {"cornell_teapot3": "cornell_teapot3_32x24_r4", "cornell_official": "cornell_official_64x48_r1", "basic": "basic_32x24_r4",
+                 "triangles": "triangles_32x24_r4", "twoLights": "twoLights_32x24_r4", "threeLights": "threeLights_32x24_r1",
+                 "own_gems": "own_gems_48x36_r4", "own_studio": "own_studio_48x36_r4", "own_flat": "own_flat_32x24_r4"}
 BYTES_PER_SAMPLE_FUSED = 24.0       # seed 4 in + 4 out, accumulator 16 out (a frame's first pass does not read it)
 BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0
 PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA-counted)
 PEAK_HBM_GBS = 8000.0
-# VALU wave-instructions per sample-lane (SQ_INSTS_VALU / SQ_WAVES, profiles/r1m_final) and the issue rate one SIMD sustains on
+# VALU wave-instructions per sample-lane (SQ_INSTS_VALU / SQ_WAVES, profiles/r2a_amd_opencl_contract) and the issue rate one SIMD sustains on
 # plain fp32 VOP2 streams at 8 waves (profiles/micro/valu_rate.hip: 2.4 nominal cycles per wave-instruction; the 2-cycle figure is the spec)
-VALU_INSTR_PER_SAMPLE = {8: 25170.0}
+VALU_INSTR_PER_SAMPLE = {8: 19784.0}
 SIMDS, NOMINAL_HZ, MEASURED_ISSUE_CYCLES = 1024, 2.4e9, 2.4
-# HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r1d_park_lds: FETCH_SIZE x 2 + WRITE_SIZE,
+# HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r2a_amd_opencl_contract: FETCH_SIZE x 2 + WRITE_SIZE,
 # KiB -> bytes; gfx950 halves FETCH_SIZE on wide coalesced reads, MI355X_MICROARCH.md).  Valid for the default workload only.
-TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 2.12e9, "write_bytes": 10.62e9, "source": "profiles/r1m_final/pmc_summary.json"}
+TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 2.12e9, "write_bytes": 10.62e9, "source": "profiles/r2a_amd_opencl_contract/pmc_summary.json"}
 
 
-def cpu_baseline(packed_json, log, bounces):
+def cpu_baseline(packed_json, log, bounces, rpp=256):
     """The CPU oracle (our plain-C restatement, OpenMP) on a bounded sample.  Threads = the CPUs this process may really use: the
     affinity mask capped by the cgroup CPU quota (oracle/a10_pass.py cpu_budget); `cores` reports that number."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import a10_pass as A
     d = json.loads(packed_json)
-    w, h, rpp = 480, 270, 256
+    w, h = 480, 270
     cam = list(d["cam"])
     cam[14], cam[15] = float(w), float(h)   # same 16:9 frustum, 1/4 of the pixels per side
     d.update(cam=cam, width=w, height=h, rays_per_pixel=rpp)
@@ -68,7 +73,8 @@ def cpu_baseline(packed_json, log, bounces):
     dt = time.perf_counter() - t0
     log(f"cpu_baseline: {sc.total_rays} samples in {dt:.2f} s on {cores} threads")
     return {"value": round(sc.total_rays / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "host_cpus_visible": os.cpu_count(), "kind": "port",
-            "sample": f"cornell.xml {w}x{h} rpp{rpp} 1 pass {bounces} bounces ({sc.total_rays} samples, {dt:.1f} s wall)"}
+            "sample": f"the same scene at {w}x{h} rpp{rpp} 1 pass {bounces} bounces ({sc.total_rays} samples, {dt:.1f} s wall)",
+            "note": "the CPU checker models v_rsq_f32 / v_sqrt_f32 through 2 x 16 MB measured tables (oracle/cl_numerics.h): bit-exact, cache-unfriendly"}
 
 
 def main():
@@ -78,11 +84,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--rpp", type=int, default=256)
+    ap.add_argument("--rpp", type=int, default=None, help="rays per pixel (a square); default 256 for the headline scene, 16 with --scene")
+    ap.add_argument("--scene", default="cornell", help="cornell (BASELINE configs[3], the default) or another A10 scene the fixtures carry: "
+                    "cornell_teapot3 (two grid meshes, two lights), own_gems, twoLights, ...")
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--no-depth5", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
+    if args.rpp is None:
+        args.rpp = 256 if args.scene == "cornell" else 16
 
     # stdout carries exactly one line, the JSON: native libraries that print banners to fd 1 (RCCL does at init) go to stderr
     sys.stdout.flush()
@@ -115,7 +125,13 @@ def main():
 
     name = f"scene_cornell_{args.width}x{args.height}_r{args.rpp}.json"
     path = os.path.join(ROOT, "tests", "golden", name)
-    if os.path.exists(path):
+    if args.scene != "cornell":
+        if args.scene not in SCENE_FIXTURE:
+            raise SystemExit(f"--scene {args.scene}: known scenes are cornell, " + ", ".join(sorted(SCENE_FIXTURE)))
+        fxs = np.load(os.path.join(ROOT, "tests", "golden", SCENE_FIXTURE[args.scene] + ".npz"))
+        packed = json.dumps(scene.PackedScene(bytes(fxs["scene_json"]).decode()).resized(args.width, args.height, args.rpp).d)
+        sc = scene.PackedScene(packed)
+    elif os.path.exists(path):
         packed = open(path).read()
         sc = scene.PackedScene(packed)
     else:  # other sizes: same scene, camera re-packed for the size
@@ -173,39 +189,42 @@ def main():
     fused_ms = float(np.mean([k[0] for k in kern_ms]))
     resolve_ms = float(np.mean([k[1] for k in kern_ms]))
     local_samples = fr.nrays
-    flops = FLOPS_PER_SAMPLE.get(args.bounces, FLOPS_PER_SAMPLE[5] * (1 + args.bounces) / 6.0)
-    valu_tf = flops * local_samples / (fused_ms * 1e-3) / 1e12
+    fps_table = FLOPS_PER_SAMPLE.get(args.scene)
+    flops = None if fps_table is None else fps_table.get(args.bounces, fps_table[5] * (1 + args.bounces) / 6.0)
+    valu_tf = (flops or 0.0) * local_samples / (fused_ms * 1e-3) / 1e12
+    has_grids = any(m["nslabs"] > 1 for m in sc.d.get("meshes", [])) or sc.d.get("n_slabs", 1) > 1
+    kernel_name = "pt::k_fusedPass<true,true>" if has_grids else "pt::k_fusedPass<true,false>"
     hbm_gbs = BYTES_PER_SAMPLE_FUSED * local_samples / (fused_ms * 1e-3) / 1e9
 
-    default_wl = (world == 1 and (sc.width, sc.height, sc.rpp, args.bounces) == (1920, 1080, 256, 8))
+    default_wl = (world == 1 and args.scene == "cornell" and (sc.width, sc.height, sc.rpp, args.bounces) == (1920, 1080, 256, 8))
     traffic = (TRAFFIC_DEFAULT_WORKLOAD["fetch_bytes"] + TRAFFIC_DEFAULT_WORKLOAD["write_bytes"]) if default_wl else None
     out = {
         "metric": "Msamples/sec (pixels x spp) at 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "fps": round(args.steps / dt, 3),
-        "config": {"workload": f"A10 cornell.xml path trace {sc.width}x{sc.height}, {sc.rpp} spp (16x16 lens grid), 1 pass, "
+        "config": {"workload": f"A10 {args.scene}.xml path trace {sc.width}x{sc.height}, {sc.rpp} spp ({int(round(sc.rpp ** 0.5))}x{int(round(sc.rpp ** 0.5))} lens grid), 1 pass, "
                                f"{args.bounces} bounces, thin lens; fused mirt_render_pass + copyToPixel"
                                + (f"; {world} row tiles + RCCL all_gather of RGBA8" if world > 1 else ""),
                    "width": sc.width, "height": sc.height, "rays_per_pixel": sc.rpp, "bounces": args.bounces,
                    "parallelism": f"rows/{world}"},
-        "roofline": {"kernel": "pt::k_fusedPass<true,false>", "bound": "valu", "achieved": round(valu_tf, 2), "peak": PEAK_VALU_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(valu_tf / PEAK_VALU_TFLOPS, 4), "traffic": traffic,
+        "roofline": {"kernel": kernel_name, "bound": "valu", "achieved": round(valu_tf, 2) if flops else None, "peak": PEAK_VALU_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(valu_tf / PEAK_VALU_TFLOPS, 4) if flops else None, "traffic": traffic,
                      "flops_per_sample": flops, "launch_ms": round(fused_ms, 3), "resolve_ms": round(resolve_ms, 3)},
-        "issue": None if args.bounces not in VALU_INSTR_PER_SAMPLE else {
+        "issue": None if (args.bounces not in VALU_INSTR_PER_SAMPLE or args.scene != "cornell") else {
             "what": "VALU wave-instructions issued per second by the kernel vs what 1024 SIMDs sustain on plain fp32 VOP2 streams",
             "achieved_Ginstr_s": round(VALU_INSTR_PER_SAMPLE[args.bounces] * local_samples / 64.0 / (fused_ms * 1e-3) / 1e9, 1),
             "attainable_Ginstr_s": round(SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES / 1e9, 1), "spec_Ginstr_s": round(SIMDS * NOMINAL_HZ / 2.0 / 1e9, 1),
             "frac_of_attainable": round(VALU_INSTR_PER_SAMPLE[args.bounces] * local_samples / 64.0 / (fused_ms * 1e-3) / (SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES), 4),
-            "source": "profiles/r1m_final/pmc_summary.json, profiles/micro/README.md"},
-        "roofline_hbm": {"kernel": "pt::k_fusedPass<true,false>", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
+            "source": "profiles/r2a_amd_opencl_contract/pmc_summary.json, profiles/micro/README.md"},
+        "roofline_hbm": {"kernel": kernel_name, "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
                          "traffic_note": "algorithmic 12.7 GB/launch (seeds in + out, accumulator out); measured 2.12 + 10.62 GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes): no re-reads, no scratch",
                          "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(packed, log, args.bounces)
-    if rank == 0 and world == 1 and args.bounces == 8 and not args.no_depth5:
+        out["cpu_baseline"] = cpu_baseline(packed, log, args.bounces, sc.rpp)
+    if rank == 0 and world == 1 and args.bounces == 8 and not args.no_depth5 and fps_table:
         # the reference's own depth (five bounces), same frame, two untimed-warmup-free steps: reported beside the headline
         t5 = []
         for _ in range(2):
@@ -214,7 +233,7 @@ def main():
             fr.execute_render(bounces=5, fresh=True)
             t5.append(ctx.pass_timing()[0])
         out["depth5"] = {"launch_ms": round(float(np.mean(t5)), 3), "Msamples_per_s_kernel": round(fr.nrays / np.mean(t5) / 1e3, 1),
-                         "flops_per_sample": FLOPS_PER_SAMPLE[5], "frac": round(FLOPS_PER_SAMPLE[5] * fr.nrays / (np.mean(t5) * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4)}
+                         "flops_per_sample": fps_table[5], "frac": round(fps_table[5] * fr.nrays / (np.mean(t5) * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4)}
     fr.release()
     ctx.destroy()
     if use_dist:
