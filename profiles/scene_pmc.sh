@@ -12,7 +12,7 @@ import csv, glob, sys, collections
 agg=collections.defaultdict(list)
 for f in glob.glob(sys.argv[1]+'/*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'k_fusedPass<true>' in r['Kernel_Name'] or 'k_fusedPassILb1' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'k_fusedPass<true' in r['Kernel_Name'] or 'k_fusedPassILb1' in r['Kernel_Name'] or 'k_fusedPassSM' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
 w=sum(agg['SQ_WAVES'])/len(agg['SQ_WAVES'])
 print(' '.join(f"{k.replace('SQ_','')}={sum(v)/len(v)/w:.0f}" for k,v in sorted(agg.items())))
 PY
