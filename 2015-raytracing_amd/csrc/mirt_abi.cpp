@@ -1204,12 +1204,15 @@ int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cel
     const uint64_t cells = (uint64_t)d->n_slabs * d->n_slabs * d->n_slabs;
     if ((rc = new_owned(ctx, (cells + 1) * 4, cell_offsets))) return rc;
     uint32_t* ord = nullptr;
+    uint64_t slots = 0;
     hipError_t e = pt::grid_build(ctx->stream, (int)d->kind, d->count ? (const double*)d->prims_f64->ptr : nullptr, d->count, d->bounds, d->n_slabs,
-                                  (uint32_t*)(*cell_offsets)->ptr, &ord, total);
-    if (e != hipSuccess) {
+                                  (uint32_t*)(*cell_offsets)->ptr, &ord, total, &slots);
+    if (e != hipSuccess || slots > pt::kMaxGridSlots) {
         mirt_buf_release(*cell_offsets);
         *cell_offsets = nullptr;
-        return fail(ctx, MIRT_E_DEVICE, "mirt_grid_build: %s", hipGetErrorString(e));
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, MIRT_E_DEVICE, "mirt_grid_build: %s", hipGetErrorString(e)); }
+        return fail(ctx, MIRT_E_RANGE, "mirt_grid_build: the grid would hold %llu (cell, primitive) slots; at most %llu are supported -- use fewer slabs",
+                    (unsigned long long)slots, (unsigned long long)pt::kMaxGridSlots);
     }
     // adopt the order array as an owned buffer
     mirt_buf* ob = new mirt_buf();

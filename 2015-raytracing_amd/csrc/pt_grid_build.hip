@@ -42,7 +42,7 @@ __device__ __forceinline__ void clamp_range(const double* lo, const double* hi, 
 }
 
 // kind 0: spheres, prim = (cx, cy, cz, r) fp64; kind 1: triangles, prim = 9 fp64 (p0, p1, p2)
-__global__ void __launch_bounds__(256) k_cellRanges(int kind, const double* prims, uint32_t count, GridDims g, int* ranges, uint32_t* ncells) {
+__global__ void __launch_bounds__(256) k_cellRanges(int kind, const double* prims, uint32_t count, GridDims g, int* ranges, uint64_t* ncells) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     double lo[3], hi[3];
@@ -63,18 +63,18 @@ __global__ void __launch_bounds__(256) k_cellRanges(int kind, const double* prim
     }
     int r[6];
     clamp_range(lo, hi, g, r);
-    uint32_t nc = 1;
-    for (int c = 0; c < 3; ++c) nc *= (r[3 + c] >= r[c]) ? (uint32_t)(r[3 + c] - r[c] + 1) : 0u;
+    uint64_t nc = 1;   // up to n^3 = 2^30 cells per primitive, times up to 2^32 primitives: counted in 64 bits, checked on the host
+    for (int c = 0; c < 3; ++c) nc *= (r[3 + c] >= r[c]) ? (uint64_t)(r[3 + c] - r[c] + 1) : 0ull;
     for (int c = 0; c < 6; ++c) ranges[6u * (size_t)i + c] = r[c];
     ncells[i] = nc;
 }
 
-__global__ void __launch_bounds__(256) k_emitPairs(const int* ranges, const uint32_t* start, uint32_t count, uint32_t n,
+__global__ void __launch_bounds__(256) k_emitPairs(const int* ranges, const uint64_t* start, uint32_t count, uint32_t n,
                                                     uint32_t* keys, uint32_t* vals, uint32_t* cell_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int* r = ranges + 6u * (size_t)i;
-    uint32_t k = start[i];
+    uint64_t k = start[i];   // < 2^31 in total: grid_build refuses larger slot counts before this kernel is launched
     for (int z = r[2]; z <= r[5]; ++z)
         for (int y = r[1]; y <= r[4]; ++y)
             for (int x = r[0]; x <= r[3]; ++x) {
@@ -127,56 +127,62 @@ __global__ void __launch_bounds__(256) k_gatherU32(const uint32_t* order, uint32
 static inline dim3 g1(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 // Returns hipSuccess and the number of (cell, primitive) slots.  `offsets` must hold n^3 + 1 uints.  `order_out` receives
-// a device allocation (hipMalloc) of `*total` uints that the caller owns.
+// a device allocation (hipMalloc) of `*total` uints that the caller owns.  `*slots_needed` always receives the exact 64-bit slot
+// count; when it exceeds kMaxGridSlots nothing is emitted (order_out stays null, total 0) and the caller reports MIRT_E_RANGE.
+// Device memory: one arena for the counting phase, one for the sort -- three hipMalloc per build including the result.
 hipError_t grid_build(hipStream_t s, int kind, const double* prims, uint32_t count, const double bounds6[6], uint32_t n,
-                      uint32_t* offsets, uint32_t** order_out, uint32_t* total) {
+                      uint32_t* offsets, uint32_t** order_out, uint32_t* total, uint64_t* slots_needed) {
     GridDims g;
     g.n = n;
     for (int c = 0; c < 3; ++c) { g.bmin[c] = bounds6[c]; g.w[c] = (bounds6[3 + c] - bounds6[c]) / (double)n; }
     const uint64_t cells = (uint64_t)n * n * n;
     *order_out = nullptr;
     *total = 0;
-    int* ranges = nullptr;
-    uint32_t *ncells = nullptr, *start = nullptr, *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *cell_count = nullptr;
-    void* tmp = nullptr;
-    size_t tmp_bytes = 0, need = 0;
+    *slots_needed = 0;
+    char *arena1 = nullptr, *arena2 = nullptr;
     hipError_t rc = hipSuccess;
-    auto cleanup = [&]() {
-        (void)hipFree(ranges); (void)hipFree(ncells); (void)hipFree(start); (void)hipFree(keys); (void)hipFree(vals); (void)hipFree(keys2);
-        (void)hipFree(cell_count); (void)hipFree(tmp);
-    };
-#define GB_TRY(e) do { rc = (e); if (rc != hipSuccess) { cleanup(); return rc; } } while (0)
-    GB_TRY(hipMalloc(&cell_count, (cells + 1) * 4));
+    auto cleanup = [&]() { (void)hipFree(arena1); (void)hipFree(arena2); };
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+#define GB_TRY(e) do { rc = (e); if (rc != hipSuccess) { cleanup(); if (*order_out) { (void)hipFree(*order_out); *order_out = nullptr; } return rc; } } while (0)
+    // ---- phase 1: per-primitive cell ranges and counts, their 64-bit scan, the per-cell counters
+    size_t scan1 = 0, scan2 = 0;
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan1, (uint64_t*)nullptr, (uint64_t*)nullptr, (int)count + 1, s));
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan2, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)cells + 1, s));
+    const size_t o_ranges = 0, o_ncells = o_ranges + up((size_t)count * 24), o_start = o_ncells + up(((size_t)count + 1) * 8),
+                 o_cellcnt = o_start + up(((size_t)count + 1) * 8), o_tmp = o_cellcnt + up((cells + 1) * 4),
+                 bytes1 = o_tmp + up(scan1 > scan2 ? scan1 : scan2);
+    GB_TRY(hipMalloc((void**)&arena1, bytes1));
+    int* ranges = (int*)(arena1 + o_ranges);
+    uint64_t *ncells = (uint64_t*)(arena1 + o_ncells), *start = (uint64_t*)(arena1 + o_start);
+    uint32_t* cell_count = (uint32_t*)(arena1 + o_cellcnt);
+    void* tmp = arena1 + o_tmp;
     GB_TRY(hipMemsetAsync(cell_count, 0, (cells + 1) * 4, s));
     if (count) {
-        GB_TRY(hipMalloc(&ranges, (size_t)count * 24));
-        GB_TRY(hipMalloc(&ncells, ((size_t)count + 1) * 4));
-        GB_TRY(hipMalloc(&start, ((size_t)count + 1) * 4));
-        GB_TRY(hipMemsetAsync(ncells, 0, ((size_t)count + 1) * 4, s));
+        GB_TRY(hipMemsetAsync(ncells, 0, ((size_t)count + 1) * 8, s));
         hipLaunchKernelGGL(k_cellRanges, g1(count), dim3(256), 0, s, kind, prims, count, g, ranges, ncells);
-        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, ncells, start, (int)count + 1, s));
-        tmp_bytes = need;
-        GB_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-        GB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ncells, start, (int)count + 1, s));
-        uint32_t tot = 0;
-        GB_TRY(hipMemcpyAsync(&tot, start + count, 4, hipMemcpyDeviceToHost, s));
+        size_t need = scan1;
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, need, ncells, start, (int)count + 1, s));
+        uint64_t tot = 0;
+        GB_TRY(hipMemcpyAsync(&tot, start + count, 8, hipMemcpyDeviceToHost, s));
         GB_TRY(hipStreamSynchronize(s));
-        *total = tot;
+        *slots_needed = tot;
+        if (tot > kMaxGridSlots) { cleanup(); return hipSuccess; }   // the caller turns this into MIRT_E_RANGE; nothing was emitted
+        *total = (uint32_t)tot;
         if (tot) {
-            GB_TRY(hipMalloc(&keys, (size_t)tot * 4));
-            GB_TRY(hipMalloc(&vals, (size_t)tot * 4));
-            GB_TRY(hipMalloc(&keys2, (size_t)tot * 4));
-            GB_TRY(hipMalloc((void**)order_out, (size_t)tot * 4));
-            hipLaunchKernelGGL(k_emitPairs, g1(count), dim3(256), 0, s, ranges, start, count, n, keys, vals, cell_count);
+            // ---- phase 2: (cell, primitive) pairs, stable sort by cell
             int bits = 1;
             while ((1ull << bits) < cells && bits < 32) ++bits;
-            GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, keys2, vals, *order_out, (int)tot, 0, bits, s));
-            if (need > tmp_bytes) { (void)hipFree(tmp); tmp = nullptr; GB_TRY(hipMalloc(&tmp, need)); tmp_bytes = need; }
-            GB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, need, keys, keys2, vals, *order_out, (int)tot, 0, bits, s));
+            size_t sort_tmp = 0;
+            GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)tot, 0, bits, s));
+            const size_t o_keys = 0, o_vals = o_keys + up((size_t)tot * 4), o_keys2 = o_vals + up((size_t)tot * 4), o_stmp = o_keys2 + up((size_t)tot * 4);
+            GB_TRY(hipMalloc((void**)&arena2, o_stmp + up(sort_tmp)));
+            GB_TRY(hipMalloc((void**)order_out, (size_t)tot * 4));
+            uint32_t *keys = (uint32_t*)(arena2 + o_keys), *vals = (uint32_t*)(arena2 + o_vals), *keys2 = (uint32_t*)(arena2 + o_keys2);
+            hipLaunchKernelGGL(k_emitPairs, g1(count), dim3(256), 0, s, ranges, start, count, n, keys, vals, cell_count);
+            GB_TRY(hipcub::DeviceRadixSort::SortPairs(arena2 + o_stmp, sort_tmp, keys, keys2, vals, *order_out, (int)tot, 0, bits, s));
         }
     }
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, cell_count, offsets, (int)cells + 1, s));
-    if (need > tmp_bytes) { (void)hipFree(tmp); tmp = nullptr; GB_TRY(hipMalloc(&tmp, need)); tmp_bytes = need; }
+    size_t need = scan2;
     GB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, need, cell_count, offsets, (int)cells + 1, s));
     GB_TRY(hipStreamSynchronize(s));
     cleanup();

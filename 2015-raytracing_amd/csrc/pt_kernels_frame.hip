@@ -106,10 +106,29 @@ __global__ void __launch_bounds__(256) k_a04_meshTrace(uchar4* pixels, F16 cam16
     Ray ray = load_ray48(&rays[pix]);
     float champ_t = PT_INF, cb = 0.0f, cg = 0.0f;
     uint32_t champ_i = t_size;
-    for (uint32_t i = 0; i < t_size; ++i) {
-        float t, b, g;
-        bool hit = tri_test<TRI_A04, false>(ray.o, ray.d, ray.mint, ray.maxt, prep[3u * i], prep[3u * i + 1], prep[3u * i + 2], t, b, g);
-        if (hit && t < champ_t) { champ_t = t; champ_i = i; cb = b; cg = g; }
+    // interTriangle (A04 code.cl:146-184) on the prepared triangle, staged: the 64 lanes of a wave are 2 x 32 adjacent pixels, and
+    // almost every one of a mesh's small triangles is missed by all of them at an early rejection.  After each of the reference's
+    // early-outs a wave ballot asks whether ANY lane is still in; if none is, the rest of the test is skipped for the wave.  Lanes
+    // that are still in compute exactly the values the straight-line test computes, so nothing changes but the work.
+    const float4* __restrict__ p = prep;
+    for (uint32_t i = 0; i < t_size; ++i, p += 3) {
+        const float4 A = p[0], B = p[1], C = p[2];
+        const f3 p0 = mk3(A.x, A.y, A.z), e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z), n = mk3(A.w, B.w, C.w);
+        const float div = dot3(n, ray.d);
+        bool in = !(div <= 0);                                                   // code.cl:153
+        if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;
+        const float idiv = rcp_exact(div, !in);                                  // 1.0f / div, bit for bit (pt_numerics.hpp)
+        const f3 s = sub3(ray.o, p0);
+        const float beta = dot3(cross3(s, ray.d), e2) * idiv;
+        in = in & !(beta < 0.0f) & !(beta > 1.0f);                               // :161
+        if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;
+        const float gamma = dot3(cross3(s, e1), ray.d) * idiv;
+        const float gb = gamma + beta;
+        in = in & !(gamma < 0.0f) & !(gamma > 1.0f) & !(gb < 0.0f) & !(gb > 1.0f);   // :169-170 (A04 also rejects gamma > 1)
+        if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;
+        const float t = dot3(cross3(s, e2), e1) * -idiv;
+        in = in & (t > ray.mint) & (t < ray.maxt);                               // open interval, :177
+        if (in && t < champ_t) { champ_t = t; champ_i = i; cb = beta; cg = gamma; }
     }
     if (champ_i >= t_size) return;
     rays[pix].maxt = champ_t;

@@ -81,8 +81,9 @@ void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word);
 
 // ---- uniform-grid build on the device (pt_grid_build.hip) -------------------------------------------
+constexpr uint64_t kMaxGridSlots = 0x7FFFFFFFull;   // (cell, primitive) slots one grid may hold: the sort and every consumer index them with 31 bits
 hipError_t grid_build(hipStream_t s, int kind, const double* prims, uint32_t count, const double bounds6[6], uint32_t n,
-                      uint32_t* offsets, uint32_t** order_out, uint32_t* total);
+                      uint32_t* offsets, uint32_t** order_out, uint32_t* total, uint64_t* slots_needed);
 void launch_gatherTriangles(hipStream_t s, const uint32_t* order, uint32_t total, const double* pos9, const double* nor9,
                             int nsteps, const int* ops, const double* vecs, float pad_w, void* pos_out, void* nor_out);
 void launch_gatherSpheres(hipStream_t s, const uint32_t* order, uint32_t total, const double* sph4, void* out);

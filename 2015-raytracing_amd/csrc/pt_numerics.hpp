@@ -3,8 +3,8 @@
 // OpenCL C leaves the bits of its built-in math to the implementation, so the "reference output" of A10 code.cl only exists
 // once an implementation is named.  The one named (DESIGN.md "Numerics contract") is the one that exists for this hardware:
 // AMD's own OpenCL C toolchain -- clang in OpenCL mode + the ROCm OpenCL built-in library (opencl.bc / ocml.bc), options
-// -cl-std=CL1.2 -O3 -cl-fp32-correctly-rounded-divide-sqrt.  The reference's code.cl compiled that way
-// (oracle/_ref/a10_gfx950.hsaco, run on the MI355X by oracle/ref_gpu.py) is what these kernels equal bit for bit:
+// -cl-std=CL1.2 -O3 -cl-fp32-correctly-rounded-divide-sqrt.  The reference's code.cl compiled that way (a gfx950 code object the
+// test tree builds and runs on the MI355X itself, tests/test_ref_gpu.py) is what these kernels equal bit for bit:
 //   + - *      IEEE binary32, RNE, denormals kept
 //   a*b+c      fused EXACTLY where the OpenCL front end contracts (a product feeding a sum inside one expression; the left
 //              product when both operands are products): written as explicit fmaf here, every TU builds with -ffp-contract=off

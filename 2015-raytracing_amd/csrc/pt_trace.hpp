@@ -210,8 +210,7 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         }
     }
     const float cmin = bh.tmin;
-    // FAST: finite operands, result only compared -> one v_min3_f32 (see slab1_fast)
-    const float cmax = FAST ? __builtin_fminf(__builtin_fminf(tn[0], tn[1]), tn[2]) : cl_min(cl_min(tn[0], tn[1]), tn[2]);
+    const float cmax = cl_min(cl_min(tn[0], tn[1]), tn[2]);   // one v_min3_f32
     const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
     const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
     bool done = false;
@@ -256,9 +255,19 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     ch.gamma = 0.0f;
     SphereRay sr;
     if (KIND == SPHERES) sr = sphere_ray<FAST>(ray.d);
-    Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, defer);
-    Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, defer);
-    Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, defer);
+    // Per-axis walk state kept to what the loop reads: the next plane's t, the step in t, the slab index.  The step direction and the
+    // index at which the ray leaves the grid follow from the sign of d, which is still in a register (code.cl:701-705: d >= 0 ? +1, n : -1, -1).
+    float tnx, tny, tnz, dtx, dty, dtz;
+    int sx, sy, sz;
+    {
+        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, defer);
+        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, defer);
+        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, defer);
+        tnx = ax.tnext; tny = ay.tnext; tnz = az.tnext;
+        dtx = ax.dt; dty = ay.dt; dtz = az.dt;
+        sx = ax.slab; sy = ay.slab; sz = az.slab;
+    }
+    const int nn = (int)S.n;
     // The reference walks cell by cell and, inside a cell, primitive by primitive (two nested loops per work-item).  Run that way
     // on a 64-lane wave every outer iteration costs the LONGEST list any lane holds.  Same per-lane sequence, re-phased:
     //   phase A: every lane whose list is exhausted closes its cell (stop on a hit, else step) and opens the next one -- cheap
@@ -268,9 +277,9 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     const uint32_t zs = S.n * S.n, ys = S.n;   // n <= 1024 (check_grid): 24-bit multiplies are exact
     float t = bh.tmin;
     float cmin = t;
-    // FAST: the three exits are finite and the minimum is only compared (== against them, <= against t): one v_min3_f32
-    float cmax = FAST ? __builtin_fminf(__builtin_fminf(ax.tnext, ay.tnext), az.tnext) : cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
-    uint32_t cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
+    // the three exits through v_min_f32 (OpenCL min() IS that instruction under the contract, pt_numerics.hpp)
+    float cmax = cl_min(cl_min(tnx, tny), tnz);
+    uint32_t cell = __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx;
     uint32_t i, end;
     if (staged) { i = lt[cell]; end = lt[cell + 1]; } else { i = off[cell]; end = off[cell + 1]; }
     for (;;) {
@@ -281,22 +290,25 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
             // branches cost scalar instructions, which are not the bottleneck (selects instead: 72.2 -> 77.6 ms on cornell_teapot3)
             if (ch.idx != UINT32_MAX) { alive = false; break; }
             t = cmax;
-            if (t == ax.tnext) {
-                ax.tnext += ax.dt;
-                ax.slab += ax.dslab;
-                if (t >= bh.tmax || ax.slab == ax.limit) { alive = false; break; }
-            } else if (t == ay.tnext) {
-                ay.tnext += ay.dt;
-                ay.slab += ay.dslab;
-                if (t >= bh.tmax || ay.slab == ay.limit) { alive = false; break; }
+            if (t == tnx) {
+                tnx += dtx;
+                const bool fwd = ray.d.x >= 0;
+                sx += fwd ? 1 : -1;
+                if (t >= bh.tmax || sx == (fwd ? nn : -1)) { alive = false; break; }
+            } else if (t == tny) {
+                tny += dty;
+                const bool fwd = ray.d.y >= 0;
+                sy += fwd ? 1 : -1;
+                if (t >= bh.tmax || sy == (fwd ? nn : -1)) { alive = false; break; }
             } else {
-                az.tnext += az.dt;
-                az.slab += az.dslab;
-                if (t >= bh.tmax || az.slab == az.limit) { alive = false; break; }
+                tnz += dtz;
+                const bool fwd = ray.d.z >= 0;
+                sz += fwd ? 1 : -1;
+                if (t >= bh.tmax || sz == (fwd ? nn : -1)) { alive = false; break; }
             }
             cmin = t;
-            cmax = FAST ? __builtin_fminf(__builtin_fminf(ax.tnext, ay.tnext), az.tnext) : cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
-            cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
+            cmax = cl_min(cl_min(tnx, tny), tnz);
+            cell = __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx;
             if (staged) { i = lt[cell]; end = lt[cell + 1]; } else { i = off[cell]; end = off[cell + 1]; }
         }
         if (!alive) break;

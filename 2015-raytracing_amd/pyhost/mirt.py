@@ -97,6 +97,14 @@ SYMBOLS = {
     "mirt_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mirt_graph_release": (C.c_int, [C.c_void_p]),
     "mirt_debug_numerics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mirt_buf_invalidate": (C.c_int, [C.c_void_p]),
+    "mirt_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "mirt_group_size": (C.c_int, [C.c_void_p]),
+    "mirt_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "mirt_group_destroy": (C.c_int, [C.c_void_p]),
+    "mirt_group_finish": (C.c_int, [C.c_void_p]),
+    "mirt_tile_rows": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mirt_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p, C.c_int, C.c_int]),
 }
 
 
@@ -182,13 +190,17 @@ class Kernel:
 class Context:
     """webcl.createContext(device) + ctx.createCommandQueue()."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _handle=None):
+        if _handle is not None:            # a context owned by a DeviceGroup
+            self.h, self.device, self.owned = C.c_void_p(_handle), device, False
+            return
         h = C.c_void_p()
         rc = lib().mirt_ctx_create(device, C.byref(h))
         if rc != 0:
             raise MirtError(rc, lib().mirt_last_error(None).decode())
         self.h = h
         self.device = device
+        self.owned = True
 
     def _chk(self, rc):
         if rc != 0:
@@ -431,3 +443,39 @@ class DeviceScene:
         for b in self.bufs:
             b.release()
         self.bufs = []
+
+
+class DeviceGroup:
+    """mirt_group: N contexts in one process (one per device) + mirt_gather, the one exchange of the path."""
+
+    def __init__(self, devices):
+        ids = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = lib().mirt_group_create(ids, len(devices), C.byref(h))
+        if rc != 0:
+            raise MirtError(rc, lib().mirt_last_error(None).decode())
+        self.h = h
+        self.contexts = [Context(d, _handle=lib().mirt_group_ctx(h, i)) for i, d in enumerate(devices)]
+
+    def tile_rows(self, height, index):
+        r0, n = C.c_uint32(), C.c_uint32()
+        lib().mirt_tile_rows(height, len(self.contexts), index, C.byref(r0), C.byref(n))
+        return r0.value, n.value
+
+    def gather(self, tiles, tile_bytes, out, root=0, use_rccl=False):
+        n = len(self.contexts)
+        hs = (C.c_void_p * n)(*[t.h for t in tiles])
+        bs = (C.c_size_t * n)(*tile_bytes)
+        rc = lib().mirt_gather(self.h, hs, bs, out.h, root, 1 if use_rccl else 0)
+        if rc != 0:
+            raise MirtError(rc, lib().mirt_last_error(self.contexts[0].h).decode())
+
+    def finish(self):
+        rc = lib().mirt_group_finish(self.h)
+        if rc != 0:
+            raise MirtError(rc, lib().mirt_last_error(self.contexts[0].h).decode())
+
+    def destroy(self):
+        if self.h:
+            lib().mirt_group_destroy(self.h)
+            self.h = None

@@ -14,8 +14,12 @@
  *     pageable memory complete before the call returns, whatever `blocking` says (the
  *     reference passes blocking=false and keeps its typed arrays alive until finish()).
  *   - one in-order HIP stream per context (A10 code.js:592 createCommandQueue()).
- *   - handles are reference-free: release exactly once; using a released handle is
- *     MIRT_E_HANDLE, not undefined behaviour (handles are validated against a live set).
+ *   - handles are reference-free: release exactly once; using a released handle -- or a
+ *     handle of the wrong kind -- is MIRT_E_HANDLE, not undefined behaviour (every handle is
+ *     validated against a live table keyed by address AND kind).
+ *   - a context owns what was created on it: mirt_ctx_destroy releases the buffers, kernels
+ *     and graphs the host left behind (the reference host never releases its bouncePaths
+ *     kernel, A10 code.js:1444-1455); those handles are MIRT_E_HANDLE afterwards.
  *   - single host thread per context (the reference is a single JS thread).
  */
 #ifndef MIRT_H
@@ -75,8 +79,13 @@ MIRT_API int mirt_finish(mirt_ctx* ctx);
 /* ---- buffers: ctx.createBuffer(flags, bytes) (A10 code.js:1083, 1117-1118, 1149, 1175-1177,
  *      1221-1224, 1268-1270, 1312, 1375, 1428), buffer.release() ----------------------- */
 MIRT_API int mirt_buf_create(mirt_ctx* ctx, size_t bytes, unsigned flags, mirt_buf** out);
-/* adopt device memory owned by the caller (a torch tensor's data_ptr); release() does not free it */
+/* adopt device memory owned by the caller (a torch tensor's data_ptr); release() does not free it.  The runtime cannot see writes
+ * made to such memory behind its back, so nothing derived from its contents is cached: cell-offset tables are re-validated and
+ * triangles re-prepared on every launch that uses a wrapped buffer as geometry. */
 MIRT_API int mirt_buf_wrap(mirt_ctx* ctx, void* device_ptr, size_t bytes, mirt_buf** out);
+/* tell the runtime that a buffer's contents were changed outside mirt_buf_write / the kernels (through mirt_buf_device_ptr, or by
+ * another stream): drops the cached validation / preparation of that buffer and invalidates recordings that relied on it */
+MIRT_API int mirt_buf_invalidate(mirt_buf* buf);
 MIRT_API int mirt_buf_release(mirt_buf* buf);
 MIRT_API size_t mirt_buf_size(const mirt_buf* buf);
 MIRT_API void* mirt_buf_device_ptr(const mirt_buf* buf);
@@ -228,12 +237,34 @@ MIRT_API int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_
  * mirt_capture_begin and mirt_capture_end every mirt_enqueue / mirt_render_pass / mirt_zero / mirt_seed_fill on the context is
  * recorded instead of run; mirt_graph_launch replays the recording with the argument values it was recorded with.  Run the sequence
  * once normally first: whatever needs a host round trip (cell-table validation, triangle preparation, scratch growth) is cached
- * by that run and refused (MIRT_E_ARG) inside a capture, as are mirt_finish, buffer reads / writes and timers. */
+ * by that run and refused (MIRT_E_ARG) inside a capture, as are mirt_finish, buffer reads / writes and timers.
+ * A recording holds raw device pointers.  Every allocation it touched is pinned by identity: mirt_graph_launch returns MIRT_E_HANDLE
+ * once one of those buffers has been released, once the context's scratch memory has been reallocated, or once geometry the
+ * recording was validated against (cell offsets, triangle positions) has been rewritten -- record the sequence again. */
 typedef struct mirt_graph mirt_graph;
 MIRT_API int mirt_capture_begin(mirt_ctx* ctx);
 MIRT_API int mirt_capture_end(mirt_ctx* ctx, mirt_graph** out);
 MIRT_API int mirt_graph_launch(mirt_ctx* ctx, mirt_graph* graph);
 MIRT_API int mirt_graph_release(mirt_graph* graph);
+
+/* ---- several devices in one process: row tiles + the one exchange of the path --------------------------------------------
+ * The reference is a single-device page (one context, one queue: A10 code.js:582, 592).  Every ray is independent, so a frame
+ * shards by pixel rows; ray ids stay global (mirt_pass_desc.row0 / nrows), which makes the frame independent of the tiling.
+ * A group is N contexts, one per device, driven from the one host thread: enqueue the tile passes on each context (launches are
+ * asynchronous), then mirt_gather assembles the tiles' buffers on the root device -- RCCL (ncclCommInitAll + one grouped
+ * ncclSend / ncclRecv exchange: N - 1 peers, N - 1 distinct xGMI links into the root) for N > 1, a device copy for N == 1
+ * (`use_rccl` != 0 forces the RCCL path even then, so a one-GPU box exercises it).  librccl is loaded on first use. */
+typedef struct mirt_group mirt_group;
+MIRT_API int mirt_group_create(const int* device_ids, int n, mirt_group** out);
+MIRT_API int mirt_group_size(const mirt_group* g);
+MIRT_API mirt_ctx* mirt_group_ctx(const mirt_group* g, int index);     /* owned by the group: do not mirt_ctx_destroy it */
+MIRT_API int mirt_group_destroy(mirt_group* g);                       /* destroys its contexts and everything created on them */
+MIRT_API int mirt_group_finish(mirt_group* g);                        /* queue.finish() on every device */
+/* contiguous row tiles whose sizes differ by at most one row (the first height % n_tiles tiles take the extra one) */
+MIRT_API void mirt_tile_rows(uint32_t height, uint32_t n_tiles, uint32_t index, uint32_t* row0, uint32_t* nrows);
+/* out[sum of tile_bytes[0..i-1] ...] = the first tile_bytes[i] bytes of tiles[i] (a buffer of context i), for every i;
+ * `out` is a buffer of context `root`.  Ordered after the work queued on each context; complete after mirt_finish(root ctx). */
+MIRT_API int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes, mirt_buf* out, int root, int use_rccl);
 
 /* ---- measurement: HIP events on the context's stream ---------------------------------- */
 MIRT_API int mirt_timer_start(mirt_ctx* ctx);

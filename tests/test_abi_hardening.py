@@ -1,0 +1,144 @@
+"""C ABI robustness (include/mirt.h "Conventions"): typed handle validation, contexts reaping what the host left behind,
+recordings pinned to the allocations they captured, 64-bit slot counting in the grid builder, device groups + gather."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+E_ARG, E_HANDLE, E_RANGE = -1, -2, -5
+
+
+@pytest.fixture()
+def M(pkg):
+    from raytracing_amd.pyhost import mirt
+    return mirt
+
+
+def code(fn, *a):
+    with pytest.raises(Exception) as e:
+        fn(*a)
+    return e.value.code
+
+
+def test_handles_are_validated_by_kind(M):
+    ctx = M.Context(0)
+    buf = ctx.buffer(64)
+    k = C.c_void_p()
+    assert M.lib().mirt_kernel_get(ctx.h, b"initAcu", C.byref(k)) == 0
+    # a kernel handle where a buffer is expected, a buffer where a kernel is expected, a context as a buffer
+    assert M.lib().mirt_kernel_set_arg_buf(k, 0, k) == E_HANDLE
+    assert M.lib().mirt_kernel_set_arg_buf(buf.h, 0, buf.h) == E_HANDLE
+    assert M.lib().mirt_buf_release(ctx.h) == E_HANDLE
+    assert M.lib().mirt_buf_size(k) == 0
+    assert M.lib().mirt_kernel_release(k) == 0 and M.lib().mirt_kernel_release(k) == E_HANDLE   # double release
+    buf.release()
+    ctx.destroy()
+
+
+def test_context_reaps_what_the_host_left_behind(M):
+    """The reference host never releases its bouncePaths kernel (A10 code.js:1444-1455: not pushed on cl_resources) and then releases
+    the context: the runtime frees the leftovers with the context and their handles turn invalid -- no leak, no dangling context."""
+    ctx = M.Context(0)
+    buf = ctx.buffer(1 << 20)
+    k = C.c_void_p()
+    assert M.lib().mirt_kernel_get(ctx.h, b"bouncePaths", C.byref(k)) == 0
+    ctx.destroy()
+    assert M.lib().mirt_kernel_set_arg(k, 3, 4, C.byref(C.c_uint32(1))) == E_HANDLE
+    assert M.lib().mirt_buf_release(buf.h) == E_HANDLE
+    assert M.lib().mirt_kernel_release(k) == E_HANDLE
+
+
+def test_a_recording_is_refused_once_its_allocations_are_gone(M):
+    ctx = M.Context(0)
+    n = 4096
+    acu, acu2 = ctx.buffer(n * 16), ctx.buffer(n * 16)
+    k = C.c_void_p()
+    assert M.lib().mirt_kernel_get(ctx.h, b"initAcu", C.byref(k)) == 0
+    M.lib().mirt_kernel_set_arg_buf(k, 0, acu.h)
+    M.lib().mirt_kernel_set_arg(k, 1, 4, C.byref(C.c_uint32(n)))
+    g1 = (C.c_size_t * 1)(n)
+    assert M.lib().mirt_enqueue(ctx.h, k, 1, g1, None) == 0
+    ctx.finish()
+    ctx.capture_begin()
+    assert M.lib().mirt_enqueue(ctx.h, k, 1, g1, None) == 0
+    graph = ctx.capture_end()
+    ctx.graph_launch(graph)                       # fine while everything it captured is alive
+    ctx.finish()
+    acu2.release()                                # an unrelated buffer: the recording is untouched
+    ctx.graph_launch(graph)
+    ctx.finish()
+    acu.release()                                 # the captured allocation: replay would write into freed memory
+    assert code(ctx.graph_launch, graph) == E_HANDLE
+    assert "record the sequence again" in ctx.last_error()
+    again = ctx.buffer(n * 16)                    # even if the allocator hands the same address out again
+    assert code(ctx.graph_launch, graph) == E_HANDLE
+    again.release()
+    ctx.destroy()                                 # reaps the kernel and the graph
+
+
+def test_a_recording_is_refused_once_its_geometry_is_rewritten(M, pkg):
+    """Cell-offset tables are validated and triangles prepared on the host side of a launch; a recording replays neither, so it pins the
+    contents it was validated against."""
+    import a10_pass as A
+    from conftest import load_fixture
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture("own_gems_48x36_r4")
+    ctx = M.Context(0)
+    gr = render.GranularRenderer(ctx, sc, seeds=A.make_seeds(sc.total_rays))
+    gr.execute_render()
+    gr.execute_render(use_graph=True)             # records the pass body
+    gr.execute_render(use_graph=True)             # replays it
+    graph = gr._graph
+    assert graph is not None
+    tri = gr.dev.meshes[0]["prims"]
+    data = tri.read(np.float32)
+    tri.write(data)                               # same bytes, new version: the prepared copy is no longer known to match
+    assert code(ctx.graph_launch, graph) == E_HANDLE
+    gr.release()
+    ctx.destroy()
+
+
+def test_grid_build_counts_slots_in_64_bits(M):
+    """Five primitives that cover every cell of a 1024^3 grid: 5 * 2^30 slots do not fit 32 bits.  Counted in 64 bits and refused."""
+    ctx = M.Context(0)
+    tri = np.tile(np.array([-9, -9, -9, 9, 9, -9, 9, -9, 9], np.float64), (5, 1))
+    assert code(ctx.grid_build, 1, tri, [-1, -1, -1, 1, 1, 1], 1024) == E_RANGE
+    assert "5368709120" in ctx.last_error()
+    off, order, total = ctx.grid_build(1, tri, [-1, -1, -1, 1, 1, 1], 8)     # the same primitives on a grid that fits
+    assert total == 5 * 512 and off.read(np.uint32)[-1] == total
+    off.release(); order.release()
+    ctx.destroy()
+
+
+@pytest.mark.parametrize("use_rccl", [False, True])
+def test_device_group_renders_row_tiles_and_gathers(M, pkg, use_rccl):
+    """mirt_group over the one device this box has: two row tiles rendered on its context, gathered into one frame (device copy, and
+    through RCCL with a one-rank communicator: ncclSend / ncclRecv to self inside one group) == the whole frame rendered at once."""
+    import a10_pass as A
+    from conftest import load_fixture
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture("cornell_32x24_r4")
+    grp = M.DeviceGroup([0])
+    ctx = grp.contexts[0]
+    assert M.lib().mirt_ctx_destroy(ctx.h) == E_ARG       # a group's context goes with the group
+    seeds = A.make_seeds(sc.total_rays)
+    assert grp.tile_rows(sc.height, 0) == (0, sc.height)
+    fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+    fr.execute_render()
+    frame = ctx.buffer(sc.width * sc.height * 4)
+    grp.gather([fr.pixel], [sc.width * sc.height * 4], frame, root=0, use_rccl=use_rccl)
+    grp.finish()
+    assert np.array_equal(frame.read(np.uint8).reshape(-1, 4), fx["pixel"])
+    # tile arithmetic: contiguous, sizes differ by at most one row, cover the image
+    for h, n in ((1080, 8), (1081, 8), (7, 8), (2160, 3)):
+        r0 = C.c_uint32(); nr = C.c_uint32(); acc = 0
+        for i in range(n):
+            M.lib().mirt_tile_rows(h, n, i, C.byref(r0), C.byref(nr))
+            assert r0.value == acc and nr.value in (h // n, h // n + 1)
+            acc += nr.value
+        assert acc == h
+    fr.release()
+    grp.destroy()
+    assert M.lib().mirt_finish(ctx.h) == E_HANDLE      # the group took its contexts with it

@@ -144,6 +144,43 @@ def resized(d, w, h):
                                        ("frame_a07_mol_3IZ4_n16_96x64", (1920, 1080)),           # molecule mode at scale: 8.9 k atoms, 16^3 grid
                                        ("frame_a07_own_mol_lattice_n6_96x64", (1920, 1080))])
 def test_full_size_frames_against_oracle(ctx, pkg, name, size):
+    _full_size(ctx, name, size)
+
+
+def regrid(a07_job, a04_job, n):
+    """The Assign07 job of the same mesh at another n_slabs: the reference host's binning (tests/test_grid_build.py's restatement,
+    itself checked against the reference host's grids the fixtures carry) over the mesh's triangles in input order."""
+    from test_grid_build import expected_grid, unique_triangles
+    tri = unique_triangles(a04_job)
+    nor = np.asarray(a04_job["normal"], np.float32).reshape(-1, 12)
+    b = np.asarray(a07_job["bounds"], np.float64)
+    off, order = expected_grid(1, tri, [b[0], b[1], b[2], b[4], b[5], b[6]], n)
+    pos = np.zeros((len(order), 3, 4), np.float32)
+    pos[:, :, :3] = tri[order].astype(np.float32).reshape(-1, 3, 3)
+    return dict(a07_job, n_slabs=n, slab_size=off.tolist(), pos=pos.ravel().tolist(), normal=nor[order].ravel().tolist(),
+                mindex=np.asarray(a04_job["mindex"], np.uint32)[order].tolist())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 32])
+def test_parliament_grid_variants_at_full_size(ctx, pkg, n):
+    """BASELINE config 3's other grid resolutions (n_slabs in {2 = the page's default, 16, 32}) at 1920x1080."""
+    from raytracing_amd.pyhost import render
+    _, g = fixture("frame_a07_parliament_n16_160x120")
+    _, flat = fixture("frame_a04_parliament_96x64")
+    d = resized(regrid(g, flat, n), 1920, 1080)
+    px, _ = render.render_frame(ctx, render.FramePacked(d))
+    want, _ = F.run_frame("oracle", F.Frame(d))
+    assert np.array_equal(px, want) and (px[:, :3].max(axis=1) > 0).mean() > 0.03
+
+
+@pytest.mark.gpu
+def test_teapot_brute_force_at_full_size(ctx, pkg):
+    """BASELINE config 2 on the reference's other mesh: teapot.json (992 triangles), 1024 x 1024, every pixel against every triangle."""
+    _full_size(ctx, "frame_a04_teapot_160x120", (1024, 1024))
+
+
+def _full_size(ctx, name, size):
     """BASELINE configs 2 and 3 at their full sizes, on the reference's house_of_parliament mesh (its packed buffers travel inside
     the fixture) and on ours: HIP frame == multithreaded CPU oracle, every pixel."""
     from raytracing_amd.pyhost import render

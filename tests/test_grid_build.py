@@ -40,10 +40,33 @@ def expected_grid(kind, prims, bounds6, n):
     return off, order
 
 
-def test_restatement_reproduces_the_reference_hosts_grids():
-    """cornell_teapot3: the fixture's cell offsets were produced by the reference's own splitMeshData (teapot n = 10, boxes n = 5);
-    rebuild them from the slot arrays' primitives."""
-    fx, sc = load_fixture("cornell_teapot3_64x48_r1")
+def frame_job(name):
+    fx = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, name + ".npz"))
+    return json.loads(bytes(fx["frame_json"]).decode())
+
+
+def unique_triangles(a04_job):
+    """[T, 9] doubles from an Assign04 job's float4-padded position array (input order, no grid)"""
+    return np.asarray(a04_job["pos"], np.float32).reshape(-1, 3, 4)[:, :, :3].reshape(-1, 9).astype(np.float64)
+
+
+@pytest.mark.parametrize("a07,a04", [("frame_a07_parliament_n16_160x120", "frame_a04_parliament_96x64"),
+                                     ("frame_a07_teapot_n2_160x120", "frame_a04_teapot_160x120"),
+                                     ("frame_a07_teapot_n8_160x120", "frame_a04_teapot_160x120")])
+def test_restatement_reproduces_the_reference_hosts_grids(a07, a04):
+    """The Assign07 fixtures carry what the reference's own splitMeshData produced (cell offsets + cell-sorted, duplicated
+    triangles: house_of_parliament at n = 16 -> 25 736 slots, teapot at n = 2 and 8); the Assign04 fixtures carry the same meshes'
+    triangles in input order.  The restatement, fed the latter, must rebuild the former exactly."""
+    g, flat = frame_job(a07), frame_job(a04)
+    tri = unique_triangles(flat)
+    b = np.asarray(g["bounds"], np.float64)
+    off, order = expected_grid(1, tri, [b[0], b[1], b[2], b[4], b[5], b[6]], g["n_slabs"])
+    assert np.array_equal(off, np.asarray(g["slab_size"], np.uint32))
+    slots = np.asarray(g["pos"], np.float32).reshape(-1, 3, 4)[:, :, :3].reshape(-1, 9)
+    assert np.array_equal(tri[order].astype(np.float32), slots)
+
+
+def test_restatement_quirks():
     # loose spheres / triangles use n = 1: every primitive lands in cell 0 unless it lies on a max face
     off, order = expected_grid(0, np.array([[0, 0, 0, 1.0], [5, 5, 5, 0.5]]), [-1, -1, -1, 5.5, 5.5, 5.5], 1)
     assert off.tolist() == [0, 2] and order.tolist() == [0, 1]
