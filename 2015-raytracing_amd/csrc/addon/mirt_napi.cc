@@ -465,6 +465,77 @@ napi_value TimerStopMs(napi_env env, napi_callback_info info) {
     return mk_num(env, ms);
 }
 
+// ---- device groups: mirt_group_create / _ctx / _destroy / _finish, mirt_tile_rows, mirt_gather -----------------------------
+napi_value GroupCreate(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    uint32_t n = 0;
+    if (napi_get_array_length(env, argv[0], &n) != napi_ok || n == 0) return throw_type(env, "groupCreate([device indices])");
+    std::vector<int> ids(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        napi_value e; uint32_t d;
+        if (napi_get_element(env, argv[0], i, &e) != napi_ok || !get_u32(env, e, &d)) return throw_type(env, "groupCreate: device indices are integers");
+        ids[i] = (int)d;
+    }
+    mirt_group* g = nullptr;
+    int rc = mirt_group_create(ids.data(), (int)n, &g);
+    if (rc) return throw_mirt(env, rc, nullptr);
+    return mk_ext(env, g);
+}
+napi_value GroupCtx(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    void* g; uint32_t i;
+    if (!get_ext(env, argv[0], &g) || !get_u32(env, argv[1], &i)) return throw_type(env, "groupCtx(group, index)");
+    mirt_ctx* c = mirt_group_ctx((mirt_group*)g, (int)i);
+    if (!c) return throw_mirt(env, MIRT_E_ARG, nullptr);
+    return mk_ext(env, c);
+}
+napi_value GroupDestroy(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* g;
+    if (!get_ext(env, argv[0], &g)) return throw_type(env, "groupDestroy(group)");
+    int rc = mirt_group_destroy((mirt_group*)g);
+    if (rc) return throw_mirt(env, rc, nullptr);
+    return undef(env);
+}
+napi_value GroupFinish(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* g;
+    if (!get_ext(env, argv[0], &g)) return throw_type(env, "groupFinish(group)");
+    int rc = mirt_group_finish((mirt_group*)g);
+    if (rc) return throw_mirt(env, rc, nullptr);
+    return undef(env);
+}
+napi_value TileRows(napi_env env, napi_callback_info info) {
+    ARGS(3);
+    uint32_t h, n, i, r0 = 0, nr = 0;
+    if (!get_u32(env, argv[0], &h) || !get_u32(env, argv[1], &n) || !get_u32(env, argv[2], &i)) return throw_type(env, "tileRows(height, nTiles, index)");
+    mirt_tile_rows(h, n, i, &r0, &nr);
+    napi_value o;
+    napi_create_object(env, &o);
+    napi_set_named_property(env, o, "row0", mk_num(env, r0));
+    napi_set_named_property(env, o, "nrows", mk_num(env, nr));
+    return o;
+}
+napi_value Gather(napi_env env, napi_callback_info info) {
+    ARGS(6);
+    void* g; void* out; uint32_t n = 0, root = 0, use_rccl = 0;
+    if (!get_ext(env, argv[0], &g) || napi_get_array_length(env, argv[1], &n) != napi_ok || !get_ext(env, argv[3], &out) ||
+        !get_u32(env, argv[4], &root) || !get_u32(env, argv[5], &use_rccl))
+        return throw_type(env, "gather(group, [tile buffers], [tile bytes], out, root, useRccl)");
+    std::vector<mirt_buf*> tiles(n);
+    std::vector<size_t> bytes(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        napi_value e; void* b; double nb;
+        if (napi_get_element(env, argv[1], i, &e) != napi_ok || !get_ext(env, e, &b)) return throw_type(env, "gather: tiles are buffers");
+        tiles[i] = (mirt_buf*)b;
+        if (napi_get_element(env, argv[2], i, &e) != napi_ok || !get_f64(env, e, &nb) || nb < 0) return throw_type(env, "gather: tile byte counts are numbers");
+        bytes[i] = (size_t)nb;
+    }
+    int rc = mirt_gather((mirt_group*)g, tiles.data(), bytes.data(), (mirt_buf*)out, (int)root, (int)use_rccl);
+    if (rc) return throw_mirt(env, rc, mirt_group_ctx((mirt_group*)g, 0));
+    return undef(env);
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"deviceCount", DeviceCount}, {"deviceName", DeviceName}, {"version", Version},
@@ -475,6 +546,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"renderPass", RenderPass}, {"gridBuild", GridBuild}, {"gridGatherTriangles", GridGatherTriangles},
         {"gridGatherSpheres", GridGatherSpheres}, {"gridGatherU32", GridGatherU32}, {"seedFill", SeedFill}, {"zero", Zero}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
         {"captureBegin", CaptureBegin}, {"captureEnd", CaptureEnd}, {"graphLaunch", GraphLaunch}, {"graphRelease", GraphRelease},
+        {"groupCreate", GroupCreate}, {"groupCtx", GroupCtx}, {"groupDestroy", GroupDestroy}, {"groupFinish", GroupFinish}, {"tileRows", TileRows}, {"gather", Gather},
     };
     for (auto& f : fns) {
         napi_value fn;

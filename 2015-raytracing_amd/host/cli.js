@@ -1,7 +1,7 @@
 #!/usr/bin/env node
 // host/cli.js -- command-line front end of the JavaScript host.
 //   node cli.js pack   <scene.xml> <width> <height> <raysPerPixel>                 -> packed kernel inputs as JSON (stdout)
-//   node cli.js render <scene.xml> <width> <height> <raysPerPixel> <passes> <out.rgba> [--granular [--graph]] [--device-grid] [--bounces N] [--seeds file.i32]
+//   node cli.js render <scene.xml> <width> <height> <raysPerPixel> <passes> <out.rgba> [--granular [--graph]] [--device-grid] [--bounces N] [--seeds file.i32] [--gpus N [--force-rccl]]
 //                                                                                   -> RGBA8 frame (+ <out>.radiance.f32) via the N-API addon
 //   node cli.js pack-frame <1|4|7> <mesh.json|mol.pdb|-> <width> <height> [nSlabs]  -> packed inputs of an Assign01/04/07 frame job (stdout)
 //   node cli.js frame      <1|4|7> <mesh.json|-> <width> <height> <nSlabs|0> <out.rgba>  -> RGBA8 frame of that job
@@ -30,6 +30,7 @@ if (cmd === "pack") {
   const opt = { granular: rest.includes("--granular"), graph: rest.includes("--graph"), deviceGrid: rest.includes("--device-grid"), bounces: 5, seeds: null };
   let i;
   if ((i = rest.indexOf("--bounces")) >= 0) opt.bounces = +rest[i + 1];
+  if ((i = rest.indexOf("--gpus")) >= 0) { opt.gpus = +rest[i + 1]; opt.forceRccl = rest.includes("--force-rccl"); }   // row tiles over N devices + gather
   if ((i = rest.indexOf("--seeds")) >= 0) { const b = fs.readFileSync(rest[i + 1]); opt.seeds = new Int32Array(b.buffer, b.byteOffset, b.length / 4); }
   const [file, w, h, rpp, passes, out] = [rest[0], +rest[1], +rest[2], +rest[3], +rest[4], rest[5]];
   const res = renderer.renderFile(file, w, h, rpp, passes, opt);

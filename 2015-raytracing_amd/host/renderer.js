@@ -229,6 +229,7 @@ class GranularRenderer {
   }
   readAcu() { const a = new Float32Array(this.totalRays * 4); this.q.enqueueReadBuffer(this.b.acu, false, 0, a.byteLength, a, []); this.q.finish(); return a; }
   release() {  // releaseCLResources (code.js:1539-1552)
+    if (this._graph) { this._graph.release(); this._graph = null; }
     Object.values(this.k).forEach((k) => k.release());
     Object.values(this.b).forEach((b) => b.release());
     this.dev.bufs.forEach((b) => b.release());
@@ -240,11 +241,12 @@ class FusedRenderer {
   constructor(packed, opt) {
     opt = opt || {};
     const p = this.p = packed;
-    this.device = pickDevice(opt.device);
-    this.ctx = webcl.createContext(this.device);
+    this.ownCtx = !opt.ctx;
+    this.device = opt.ctx ? opt.ctx.device : pickDevice(opt.device);
+    this.ctx = opt.ctx || webcl.createContext(this.device);   // opt.ctx: a context of a device group (renderTiled)
     this.q = this.ctx.createCommandQueue();
     this.row0 = opt.row0 || 0;
-    this.nrows = opt.nrows || p.height;
+    this.nrows = opt.nrows === undefined ? p.height : opt.nrows;
     this.npix = this.nrows * p.width;
     this.nrays = this.npix * p.rays_per_pixel;
     const first = this.row0 * p.width * p.rays_per_pixel;
@@ -272,8 +274,45 @@ class FusedRenderer {
   release() {
     [this.seeds, this.acu, this.pixel, this.radiance].forEach((b) => b.release());
     this.dev.bufs.forEach((b) => b.release());
-    this.q.release(); this.ctx.release();
+    this.q.release();
+    if (this.ownCtx) this.ctx.release();
   }
+}
+
+// One frame over N devices of this process: contiguous row tiles (mirt_tile_rows), global ray ids, every device runs the fused pass on
+// its tile (launches are asynchronous: the one JS thread queues them all, the devices run concurrently), then the RGBA8 and radiance
+// tiles are gathered on device 0 (group.gather: RCCL over xGMI for N > 1) and read back once.  The image is identical for every N.
+function renderTiled(packed, nDevices, passes, opt) {
+  opt = opt || {};
+  const all = webcl.getPlatforms()[0].getDevices(webcl.DEVICE_TYPE_ALL);
+  if (all.length < nDevices) throw new Error("renderTiled: " + nDevices + " devices asked for, " + all.length + " visible");
+  if (packed.rays_per_pixel === 1 && nDevices > 1) throw new Error("one ray per pixel couples the rows through seeds[col] (A10 code.cl:429): render it on one device");
+  const group = webcl.createDeviceGroup(all.slice(0, nDevices));
+  const tiles = [];
+  for (let i = 0; i < nDevices; i++) {
+    const t = group.tileRows(packed.height, i);
+    tiles.push(t.nrows ? new FusedRenderer(packed, Object.assign({}, opt, { ctx: group.contexts[i], row0: t.row0, nrows: t.nrows })) : null);
+  }
+  const live = tiles.filter((t) => t);
+  const q0 = live[0].q;
+  q0.timerStart();
+  for (let p = 0; p < passes; p++) live.forEach((t) => t.executeRender(opt.bounces));
+  const npix = packed.width * packed.height;
+  const root = group.contexts[0];
+  const frame = root.createBuffer(webcl.MEM_READ_WRITE, npix * 4), rad = root.createBuffer(webcl.MEM_READ_WRITE, npix * 16);
+  const dummy = tiles.map((t, i) => t || { pixel: group.contexts[i].createBuffer(webcl.MEM_READ_WRITE, 16), radiance: group.contexts[i].createBuffer(webcl.MEM_READ_WRITE, 16), npix: 0 });
+  group.gather(dummy.map((t) => t.pixel), dummy.map((t) => t.npix * 4), frame, 0, opt.forceRccl);
+  group.gather(dummy.map((t) => t.radiance), dummy.map((t) => t.npix * 16), rad, 0, opt.forceRccl);
+  group.finish();
+  const ms = q0.timerStopMs();
+  const pixel = new Uint8ClampedArray(npix * 4), radiance = new Float32Array(npix * 4);
+  q0.enqueueReadBuffer(frame, true, 0, pixel.length, pixel, []);
+  q0.enqueueReadBuffer(rad, true, 0, radiance.byteLength, radiance, []);
+  q0.finish();
+  const res = { pixel: pixel, radiance: radiance, ms: ms, device: live.length + " x " + live[0].device.getInfo(webcl.DEVICE_NAME), tiles: tiles.map((t) => (t ? [t.row0, t.nrows] : [0, 0])) };
+  live.forEach((t) => t.release());
+  group.release();
+  return res;
 }
 
 // per-pixel sequential fp32 sums of the per-ray accumulators (copyToPixel's order, A10 code.cl:1377-1380)
@@ -291,6 +330,7 @@ function renderFile(file, width, height, rpp, passes, opt) {
     packed = scene.packScene(sc, width, height, rpp, 1, true);
     opt = Object.assign({}, opt, { sceneObject: sc });
   } else packed = scene.packScene(scene.loadSceneFile(file, width, height), width, height, rpp);
+  if (opt.gpus) return renderTiled(packed, opt.gpus, passes, opt);
   const R = opt.granular ? new GranularRenderer(packed, opt) : new FusedRenderer(packed, opt);
   R.q.timerStart();
   for (let i = 0; i < passes; i++) R.executeRender(opt.bounces);
@@ -301,4 +341,4 @@ function renderFile(file, width, height, rpp, passes, opt) {
   return res;
 }
 
-module.exports = { GranularRenderer, FusedRenderer, renderFile, radianceSums, getLocalWS, KERNELS, setWebCL };
+module.exports = { GranularRenderer, FusedRenderer, renderFile, renderTiled, radianceSums, getLocalWS, KERNELS, setWebCL };

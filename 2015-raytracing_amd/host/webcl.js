@@ -12,7 +12,8 @@
 //   ctx.createBuffer(flags, bytes)                                     :1083, 1117-1118, ...
 //   queue.enqueueWriteBuffer / enqueueReadBuffer / enqueueNDRangeKernel / finish  :1095-1096, 1153, 1532-1533
 //   release() on everything                                            :1539-1552
-// plus one extension, queue.renderPass(desc): the whole executeRender() in one fused launch.
+// plus extensions: queue.renderPass(desc), the whole executeRender() in one fused launch; webcl.createDeviceGroup(devices), N contexts
+// in this one process with group.gather() to assemble row tiles on one device (RCCL); queue.gridBuild*, capture / launchGraph.
 //
 // There is no OpenCL compiler behind createProgram(): the kernels are built-in HIP code, looked
 // up by name.  build() scans the OpenCL C text for `__kernel void NAME(` and throws, with the
@@ -206,19 +207,38 @@ class WebCLCommandQueue {
 }
 
 class WebCLContext {
-  constructor(device) {
+  constructor(device, adopt) {
     this.device = device || new WebCLDevice(0);
-    this.h = wrap(() => native().ctxCreate(this.device.index));
+    this.grouped = !!adopt;                       // a context that belongs to a device group goes with the group
+    this.h = adopt || wrap(() => native().ctxCreate(this.device.index));
   }
   createCommandQueue() { return new WebCLCommandQueue(this); }
   createProgram(source) { return new WebCLProgram(this, source); }
   createBuffer(flags, bytes) { return new WebCLBuffer(this, bytes, flags); }
-  release() { if (this.h) { wrap(() => native().ctxDestroy(this.h)); this.h = null; } }
+  release() { if (this.h && !this.grouped) wrap(() => native().ctxDestroy(this.h)); this.h = null; }
+}
+
+// ---- extension: several devices in one process (mirt_group_*).  The reference is a single-device page; a frame shards by pixel rows
+// (ray ids stay global) and the one exchange is assembling the tiles on the root device: group.gather() = RCCL over xGMI for N > 1.
+class WebCLDeviceGroup {
+  constructor(devices) {
+    this.devices = devices;
+    this.h = wrap(() => native().groupCreate(devices.map((d) => d.index)));
+    this.contexts = devices.map((d, i) => new WebCLContext(d, wrap(() => native().groupCtx(this.h, i))));
+  }
+  tileRows(height, index) { return native().tileRows(height, this.devices.length, index); }
+  // out (a buffer of contexts[root]) = the first tileBytes[i] bytes of tiles[i] (a buffer of contexts[i]), back to back
+  gather(tiles, tileBytes, out, root, useRccl) {
+    wrap(() => native().gather(this.h, tiles.map((b) => b.h), tileBytes, out.h, root || 0, useRccl ? 1 : 0));
+  }
+  finish() { wrap(() => native().groupFinish(this.h)); }
+  release() { if (this.h) { wrap(() => native().groupDestroy(this.h)); this.h = null; this.contexts.forEach((c) => { c.h = null; }); } }
 }
 
 const webcl = Object.assign({
   getPlatforms() { return [new WebCLPlatform()]; },
   createContext(device) { return new WebCLContext(device); },
+  createDeviceGroup(devices) { return new WebCLDeviceGroup(devices); },
 }, C);
 
 // `window.WebCL` is only tested for existence by the reference (A10 code.js:468); `webcl` is the entry object.

@@ -198,28 +198,34 @@ class GranularRenderer:
 class FusedRenderer:
     """One mirt_render_pass per progressive pass over rows [row0, row0+nrows)."""
 
-    def __init__(self, ctx, scene, seeds=None, seed_base=0, row0=0, nrows=0, want_radiance=True):
+    def __init__(self, ctx, scene, seeds=None, seed_base=0, row0=0, nrows=None, want_radiance=True):
+        """nrows None: the whole image from row0 = 0.  nrows == 0 is an EMPTY tile (more ranks than rows): it owns minimal buffers and
+        its passes do nothing -- it is not the whole frame."""
         self.ctx, self.s = ctx, scene
         self.dev = mirt.DeviceScene(ctx, scene)
         self.row0 = row0
-        self.nrows = nrows or scene.height
+        self.nrows = scene.height if nrows is None else nrows
         self.npix = self.nrows * scene.width
         self.nrays = self.npix * scene.rpp
         self.first_ray = row0 * scene.width * scene.rpp
-        self.seeds = ctx.buffer(self.nrays * 4)
-        if seeds is not None:
-            self.seeds.write(np.asarray(seeds, np.int32)[self.first_ray:self.first_ray + self.nrays])
-        else:
-            ctx.seed_fill(self.seeds, self.first_ray, self.nrays, seed_base)
-        self.acu = ctx.buffer(self.nrays * 16)
+        self.seeds = ctx.buffer(self.nrays * 4 or 16)
+        if self.nrays:
+            if seeds is not None:
+                self.seeds.write(np.asarray(seeds, np.int32)[self.first_ray:self.first_ray + self.nrays])
+            else:
+                ctx.seed_fill(self.seeds, self.first_ray, self.nrays, seed_base)
+        self.acu = ctx.buffer(self.nrays * 16 or 16)
         ctx.zero(self.acu)
-        self.pixel = ctx.buffer(self.npix * 4)
-        self.radiance = ctx.buffer(self.npix * 16) if want_radiance else None
+        self.pixel = ctx.buffer(self.npix * 4 or 16)
+        self.radiance = ctx.buffer(self.npix * 16 or 16) if want_radiance else None
         self.passes = 1
         self._desc = None
 
     def execute_render(self, bounces=5, fresh=False):
         """fresh: first pass of a frame, accumulator initialised by the pass itself (no ctx.zero needed)."""
+        if not self.nrays:
+            self.passes += 1
+            return
         d = self.dev.pass_desc(self.seeds, self.acu, self.pixel, self.radiance, pass_index=self.passes, bounces=bounces,
                                row0=self.row0, nrows=self.nrows)
         self.ctx.render_pass(d, fresh=fresh)

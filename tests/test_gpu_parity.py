@@ -414,3 +414,15 @@ def test_error_paths(ctx, pkg):
     k.release()
     n, missing = ctx.program_check("__kernel void initAcu(__global float4* a){}\n// __kernel void ghost()\n__kernel void molTrace(){}")
     assert (n, missing) == (1, "molTrace")
+
+
+def test_empty_row_tile_is_not_the_whole_frame(ctx, pkg):
+    """more ranks than rows: a rank's tile has zero rows; its renderer owns nothing and its passes do nothing (it used to render the whole
+    frame: `nrows or height`)."""
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture("cornell_32x24_r4")
+    t = render.FusedRenderer(ctx, sc, row0=sc.height, nrows=0)
+    assert t.nrays == 0 and t.npix == 0
+    t.execute_render()
+    ctx.finish()
+    t.release()

@@ -148,6 +148,39 @@ def test_node_render_matches_compiled_reference(tmp_path, name, mode):
     assert np.array_equal(bits(rad), bits(fx["radiance"]))
 
 
+def test_node_tile_arithmetic_matches_python():
+    """mirt_tile_rows through the addon (no device needed) == pyhost/tiling.row_tiles: the Node host and the torch.distributed bench
+    cut a frame the same way."""
+    js = """
+      const a = require(process.argv[1]);
+      const out = [];
+      for (const [h, n] of [[1080, 8], [1081, 8], [2160, 3], [7, 8], [1, 1]]) { const t = []; for (let i = 0; i < n; i++) { const r = a.tileRows(h, n, i); t.push([r.row0, r.nrows]); } out.push(t); }
+      console.log(JSON.stringify(out));
+    """
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tiling", os.path.join(os.path.dirname(HOST), "pyhost", "tiling.py"))
+    tiling = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tiling)
+    got = json.loads(run_node("-e", js, os.path.join(os.path.dirname(HOST), "mirt.node")))
+    for (h, n), t in zip([(1080, 8), (1081, 8), (2160, 3), (7, 8), (1, 1)], got):
+        want = tiling.row_tiles(h, n)
+        assert [tuple(x) for x in t if x[1]] == [w for w in want if w[1]]
+        assert sum(x[1] for x in t) == h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["--gpus", "1"], ["--gpus", "1", "--force-rccl"]])
+def test_node_device_group_render(tmp_path, flags):
+    """`render --gpus N`: webcl.createDeviceGroup -> one fused renderer per device on its row tile -> group.gather on device 0 ->
+    one read-back.  On this one-GPU box N = 1 (tile == frame), once with the device copy and once through RCCL with a one-rank
+    communicator (ncclSend / ncclRecv to self): the frame must equal the compiled reference's."""
+    fx, sc = load_fixture("own_gems_48x36_r4")
+    out = str(tmp_path / "frame.rgba")
+    run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "gems.xml"), "48", "36", "4", "1", out, *flags)
+    assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), fx["pixel"])
+    assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(fx["radiance"]))
+
+
 @pytest.mark.gpu
 def test_node_progressive_passes_and_explicit_seeds(tmp_path):
     """three passes with host-supplied seeds (the reference uploads a seed array, A10 code.js:1140-1154) == oracle."""
