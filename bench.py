@@ -219,7 +219,8 @@ def main():
             "source": "profiles/r2a_amd_opencl_contract/pmc_summary.json, profiles/micro/README.md"},
         "roofline_hbm": {"kernel": kernel_name, "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
-                         "traffic_note": "algorithmic 12.7 GB/launch (seeds in + out, accumulator out); measured 2.12 + 10.62 GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes): no re-reads, no scratch",
+                         "traffic_note": ("algorithmic 12.7 GB/launch (seeds in + out, accumulator out); measured 2.12 + 10.62 GB (FETCH_SIZE x2 + WRITE_SIZE, "
+                                          "separate PMC passes): no re-reads, no scratch") if default_wl else None,
                          "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -58,17 +58,22 @@ def main():
             "meshes": [mesh(ov, of, ov, 0), mesh(ov, of, ov, 1)],
             "nodes": [{"modelMatrix": rot_y(0, 0.5, (-0.8, 0, 0)), "meshIndices": [0]}, {"modelMatrix": rot_y(40, 0.7, (0.6, 0.2, -0.3)), "meshIndices": [1]}]}
     json.dump(octa, open(os.path.join(out, "octahedra.json"), "w"))
-    # un-indexed terrain patch without nodes (exercises the identity-matrix branch): 6x6 quads
+    # un-indexed terrain patch without nodes (exercises the identity-matrix branch): 6x6 quads of a height field z = h(x, y) that faces
+    # the frame camera (which sits on +z and looks down -z, A07 code.js:55-71), with the field's own normals so the shade varies
     P, N, n = [], [], 6
-    h = lambda x, z: 0.15 * math.sin(3 * x) * math.cos(2 * z)
+    h = lambda x, y: 0.15 * math.sin(3 * x) * math.cos(2 * y)
+    def nrm(x, y):
+        gx, gy = 0.45 * math.cos(3 * x) * math.cos(2 * y), -0.30 * math.sin(3 * x) * math.sin(2 * y)
+        l = math.sqrt(gx * gx + gy * gy + 1.0)
+        return (-gx / l, -gy / l, 1.0 / l)
     for i in range(n):
         for j in range(n):
-            x0, x1, z0, z1 = i / n - 0.5, (i + 1) / n - 0.5, j / n - 0.5, (j + 1) / n - 0.5
-            q = [(x0, h(x0, z0), z0), (x1, h(x1, z0), z0), (x1, h(x1, z1), z1), (x0, h(x0, z1), z1)]
-            for tri in ((0, 2, 1), (0, 3, 2)):   # counter-clockwise seen from above -> visible from above
+            x0, x1, y0, y1 = i / n - 0.5, (i + 1) / n - 0.5, j / n - 0.5, (j + 1) / n - 0.5
+            q = [(x0, y0, h(x0, y0)), (x1, y0, h(x1, y0)), (x1, y1, h(x1, y1)), (x0, y1, h(x0, y1))]
+            for tri in ((0, 1, 2), (0, 2, 3)):   # counter-clockwise seen from +z -> visible to the camera
                 for k in tri:
                     P += [round(c, 6) for c in q[k]]
-                    N += [0.0, 1.0, 0.0]
+                    N += [round(c, 6) for c in nrm(q[k][0], q[k][1])]
     terr = {"name": "terrain", "materials": [{"diffuseReflectance": [0.4, 0.8, 0.4, 1]}],
             "meshes": [{"vertexPositions": P, "vertexNormals": N, "indices": list(range(len(P) // 3)), "materialIndex": 0}]}
     json.dump(terr, open(os.path.join(out, "terrain.json"), "w"))
