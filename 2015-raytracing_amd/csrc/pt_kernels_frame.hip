@@ -2,10 +2,11 @@
 // BASELINE.json lists as parity configurations:
 //   Assign01  raytrace                       (A01 code.cl:116-147)  one hard-coded sphere
 //   Assign04  initTrace, meshTrace           (A04 code.cl:204-215, 262-315)  brute-force ray / triangle
-//   Assign07  initTrace, meshTrace           (A07 code.cl:311-335, 475-626)  3-D uniform grid DDA, cell-parity shading
+//   Assign07  initTrace, meshTrace, molTrace (A07 code.cl:311-335, 475-626, 337-473)  3-D uniform grid DDA over triangles / atoms,
+//                                            cell-parity shading
 // Same launch shape as the reference (2-D NDRange, one work-item per pixel), same buffers
 // (Ray 48 B, uchar4 pixels, float4-padded triangles).  Triangles are read from the prepared copy
-// (pt_trace.hpp).  The molecule kernels (molTrace) of these assignments are out of scope.
+// (pt_trace.hpp).  Assign04's molTrace (brute force over atoms) is not built: its molecule mode is subsumed by Assign07's.
 #include "pt_trace.hpp"
 
 namespace pt {

@@ -189,10 +189,10 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 // FAST = false: the exact kernel (true divisions).  With `list` it recomputes the deferred samples; with list == nullptr it
 //               is the whole pass (geometry outside the guard, or PT_EXACT_FAST_DIV = 0).
 #ifndef PT_FUSED_WAVES_FAST
-#define PT_FUSED_WAVES_FAST 7   // the optimistic kernel without the grid walk: 63 VGPRs, no scratch (same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
+#define PT_FUSED_WAVES_FAST 7   // the optimistic kernel without the grid walk: 72 VGPRs, no scratch (round 1, same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
 #endif
 // GRIDS = false: every set is a single cell (n == 1: the reference's loose spheres and triangles, A10 code.js:399): only the
-//                wave-uniform loops are compiled in.  Without the DDA the register allocator needs 74 VGPRs and no scratch
+//                wave-uniform loops are compiled in.  Without the DDA the register allocator needs 72 VGPRs and no scratch
 //                (80 + 56 B with it): 157.3 -> 152.6 ms on the headline scene.  launch_fused picks it when every set has n == 1.
 // GRIDS = true : sets with n > 1 walk their grid per lane (trace_dda).
 // Tried and dropped for GRIDS: packing the rays that hit a mesh's box across the block's four waves through LDS (one wave walks
