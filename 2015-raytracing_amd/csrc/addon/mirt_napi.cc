@@ -465,6 +465,26 @@ napi_value TimerStopMs(napi_env env, napi_callback_info info) {
     return mk_num(env, ms);
 }
 
+// meshIngest(ctx, {nVertices, nCorners, firstCorner, model: Float32Array(16), normalMat: Float32Array(9), positions, normals, indices?}, posOut, norOut, bounds)
+napi_value MeshIngest(napi_env env, napi_callback_info info) {
+    ARGS(5);
+    void *c, *po, *no, *bo;
+    if (!get_ext(env, argv[0], &c) || !get_ext(env, argv[2], &po) || !get_ext(env, argv[3], &no) || !get_ext(env, argv[4], &bo))
+        return throw_type(env, "meshIngest(ctx, desc, posOut, norOut, bounds)");
+    mirt_mesh_ingest_desc d;
+    memset(&d, 0, sizeof d);
+    d.struct_size = sizeof d;
+    if (!prop_u32(env, argv[1], "nVertices", &d.n_vertices) || !prop_u32(env, argv[1], "nCorners", &d.n_corners) || !prop_u32(env, argv[1], "firstCorner", &d.first_corner) ||
+        !prop_floats(env, argv[1], "model", d.model, 16) || !prop_floats(env, argv[1], "normalMat", d.normal_mat, 9))
+        return throw_type(env, "meshIngest: desc needs nVertices, nCorners, firstCorner, model (16 floats), normalMat (9 floats)");
+    d.positions_f64 = prop_buf(env, argv[1], "positions");
+    d.normals_f64 = prop_buf(env, argv[1], "normals");
+    d.indices_u32 = prop_buf(env, argv[1], "indices");
+    int rc = mirt_mesh_ingest((mirt_ctx*)c, &d, (mirt_buf*)po, (mirt_buf*)no, (mirt_buf*)bo);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    return undef(env);
+}
+
 // ---- device groups: mirt_group_create / _ctx / _destroy / _finish, mirt_tile_rows, mirt_gather -----------------------------
 napi_value GroupCreate(napi_env env, napi_callback_info info) {
     ARGS(1);
@@ -546,7 +566,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"renderPass", RenderPass}, {"gridBuild", GridBuild}, {"gridGatherTriangles", GridGatherTriangles},
         {"gridGatherSpheres", GridGatherSpheres}, {"gridGatherU32", GridGatherU32}, {"seedFill", SeedFill}, {"zero", Zero}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
         {"captureBegin", CaptureBegin}, {"captureEnd", CaptureEnd}, {"graphLaunch", GraphLaunch}, {"graphRelease", GraphRelease},
-        {"groupCreate", GroupCreate}, {"groupCtx", GroupCtx}, {"groupDestroy", GroupDestroy}, {"groupFinish", GroupFinish}, {"tileRows", TileRows}, {"gather", Gather},
+        {"groupCreate", GroupCreate}, {"groupCtx", GroupCtx}, {"groupDestroy", GroupDestroy}, {"groupFinish", GroupFinish}, {"tileRows", TileRows}, {"gather", Gather}, {"meshIngest", MeshIngest},
     };
     for (auto& f : fns) {
         napi_value fn;

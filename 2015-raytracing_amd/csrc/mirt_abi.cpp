@@ -1258,6 +1258,36 @@ int mirt_grid_gather_triangles(mirt_ctx* ctx, mirt_buf* order, uint32_t total, m
     return MIRT_OK;
 }
 
+int mirt_mesh_ingest(mirt_ctx* ctx, const mirt_mesh_ingest_desc* d, mirt_buf* pos9_out, mirt_buf* nor9_out, mirt_buf* bounds6) {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_mesh_ingest: unknown context");
+    if (!d || d->struct_size != sizeof(mirt_mesh_ingest_desc)) return fail(ctx, MIRT_E_ARG, "mirt_mesh_ingest: null descriptor or size mismatch");
+    NOT_WHILE_CAPTURING(ctx, "mirt_mesh_ingest");
+    if (d->n_corners % 3u) return fail(ctx, MIRT_E_ARG, "mirt_mesh_ingest: %u corners is not a whole number of triangles", d->n_corners);
+    int rc;
+    if ((rc = need(ctx, "mirt_mesh_ingest positions", d->positions_f64, (uint64_t)d->n_vertices * 24))) return rc;
+    if ((rc = need(ctx, "mirt_mesh_ingest normals", d->normals_f64, (uint64_t)d->n_vertices * 24))) return rc;
+    if (d->indices_u32 && (rc = need(ctx, "mirt_mesh_ingest indices", d->indices_u32, (uint64_t)d->n_corners * 4))) return rc;
+    if (!d->indices_u32 && d->n_corners > d->n_vertices) return fail(ctx, MIRT_E_RANGE, "mirt_mesh_ingest: %u corners of an un-indexed mesh with %u vertices", d->n_corners, d->n_vertices);
+    const uint64_t end = ((uint64_t)d->first_corner + d->n_corners) * 24;
+    if ((rc = need(ctx, "mirt_mesh_ingest positions out", pos9_out, end))) return rc;
+    if ((rc = need(ctx, "mirt_mesh_ingest normals out", nor9_out, end))) return rc;
+    if ((rc = need(ctx, "mirt_mesh_ingest bounds", bounds6, 24))) return rc;
+    if ((rc = ensure_scratch(ctx, 32))) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(ctx->scratch, 0, 32, ctx->stream));
+    pt::launch_meshIngest(ctx->stream, (const double*)d->positions_f64->ptr, (const double*)d->normals_f64->ptr,
+                          d->indices_u32 ? (const uint32_t*)d->indices_u32->ptr : nullptr, d->n_vertices, d->n_corners, d->model, d->normal_mat,
+                          (double*)pos9_out->ptr + 3u * (size_t)d->first_corner, (double*)nor9_out->ptr + 3u * (size_t)d->first_corner,
+                          (float*)bounds6->ptr, (uint32_t*)ctx->scratch);
+    uint32_t flag = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&flag, (const char*)ctx->scratch + 24, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    pos9_out->version++; nor9_out->version++; bounds6->version++;
+    if (flag) return fail(ctx, MIRT_E_DATA, "mirt_mesh_ingest: an index refers past the %u vertices of the mesh", d->n_vertices);
+    return MIRT_OK;
+}
+
 static int check_order(mirt_ctx* ctx, mirt_buf* order, uint32_t total, uint64_t n_in) {
     if (!total) return MIRT_OK;
     std::vector<uint32_t> h(total);

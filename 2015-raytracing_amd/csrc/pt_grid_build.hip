@@ -126,6 +126,59 @@ __global__ void __launch_bounds__(256) k_gatherU32(const uint32_t* order, uint32
 
 static inline dim3 g1(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
+// ---- mesh ingest: parseMeshJSON (A10 tri/meshDataVersion1.js:12-78) for one (node, mesh) pair -----------------------------------
+// The reference walks nodes x meshes on the host: every vertex through the node's model matrix (gl-matrix vec3.transformMat4, :33-37,
+// for the bounds), every triangle corner de-indexed and transformed again (:52-60), its normal through the normal matrix
+// (vec3.transformMat3, :62-66).  gl-matrix keeps matrices and vectors in Float32Array: operands are the fp32 matrix entries widened to
+// double, the sums are evaluated in double left to right (JavaScript never fuses), the result is rounded to fp32 on store.  Same here,
+// one thread per corner; the outputs are the fp64 soups the grid builder consumes (every value fp32-representable).
+struct MeshXf { float m[16]; float nm[9]; };
+__device__ __forceinline__ uint32_t enc_f32(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b ^ 0x80000000u); }   // order-preserving
+__device__ __forceinline__ float dec_f32(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); }
+__device__ __forceinline__ void xf_point(const MeshXf& X, double x, double y, double z, float* o) {
+    o[0] = (float)((double)X.m[0] * x + (double)X.m[4] * y + (double)X.m[8] * z + (double)X.m[12]);
+    o[1] = (float)((double)X.m[1] * x + (double)X.m[5] * y + (double)X.m[9] * z + (double)X.m[13]);
+    o[2] = (float)((double)X.m[2] * x + (double)X.m[6] * y + (double)X.m[10] * z + (double)X.m[14]);
+}
+__global__ void __launch_bounds__(256) k_meshCorners(const double* P, const double* N, const uint32_t* idx, uint32_t n_vertices, uint32_t n_corners,
+                                                      MeshXf X, double* pos_out, double* nor_out, uint32_t* flags) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_corners) return;
+    const uint32_t v = idx ? idx[c] : c;
+    if (v >= n_vertices) { atomicOr(flags, 1u); return; }   // an index past the vertex array: reported, nothing read
+    float o[3];
+    xf_point(X, P[3u * (size_t)v], P[3u * (size_t)v + 1], P[3u * (size_t)v + 2], o);
+    pos_out[3u * (size_t)c] = o[0]; pos_out[3u * (size_t)c + 1] = o[1]; pos_out[3u * (size_t)c + 2] = o[2];
+    const double x = N[3u * (size_t)v], y = N[3u * (size_t)v + 1], z = N[3u * (size_t)v + 2];
+    nor_out[3u * (size_t)c] = (float)(x * (double)X.nm[0] + y * (double)X.nm[3] + z * (double)X.nm[6]);
+    nor_out[3u * (size_t)c + 1] = (float)(x * (double)X.nm[1] + y * (double)X.nm[4] + z * (double)X.nm[7]);
+    nor_out[3u * (size_t)c + 2] = (float)(x * (double)X.nm[2] + y * (double)X.nm[5] + z * (double)X.nm[8]);
+}
+// bounds over ALL vertices of the mesh (:33-37), not only the indexed ones; `if (v < min) min = v`: a NaN changes nothing
+__global__ void __launch_bounds__(256) k_meshBounds(const double* P, uint32_t n_vertices, MeshXf X, uint32_t* enc6) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vertices) return;
+    float o[3];
+    xf_point(X, P[3u * (size_t)v], P[3u * (size_t)v + 1], P[3u * (size_t)v + 2], o);
+    for (int c = 0; c < 3; ++c)
+        if (o[c] == o[c]) { atomicMin(&enc6[c], enc_f32(o[c])); atomicMax(&enc6[3 + c], enc_f32(o[c])); }
+}
+__global__ void k_boundsCode(float* bounds6, uint32_t* enc6, int decode) {
+    const int c = threadIdx.x;
+    if (c >= 6) return;
+    if (decode) bounds6[c] = dec_f32(enc6[c]); else enc6[c] = enc_f32(bounds6[c]);
+}
+void launch_meshIngest(hipStream_t s, const double* P, const double* N, const uint32_t* idx, uint32_t n_vertices, uint32_t n_corners,
+                       const float* m16, const float* nm9, double* pos_out, double* nor_out, float* bounds6, uint32_t* scratch8) {
+    MeshXf X;
+    for (int i = 0; i < 16; ++i) X.m[i] = m16[i];
+    for (int i = 0; i < 9; ++i) X.nm[i] = nm9[i];
+    hipLaunchKernelGGL(k_boundsCode, dim3(1), dim3(64), 0, s, bounds6, scratch8, 0);
+    if (n_vertices) hipLaunchKernelGGL(k_meshBounds, g1(n_vertices), dim3(256), 0, s, P, n_vertices, X, scratch8);
+    hipLaunchKernelGGL(k_boundsCode, dim3(1), dim3(64), 0, s, bounds6, scratch8, 1);
+    if (n_corners) hipLaunchKernelGGL(k_meshCorners, g1(n_corners), dim3(256), 0, s, P, N, idx, n_vertices, n_corners, X, pos_out, nor_out, scratch8 + 6);
+}
+
 // Returns hipSuccess and the number of (cell, primitive) slots.  `offsets` must hold n^3 + 1 uints.  `order_out` receives
 // a device allocation (hipMalloc) of `*total` uints that the caller owns.  `*slots_needed` always receives the exact 64-bit slot
 // count; when it exceeds kMaxGridSlots nothing is emitted (order_out stays null, total 0) and the caller reports MIRT_E_RANGE.

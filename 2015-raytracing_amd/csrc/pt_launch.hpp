@@ -87,6 +87,10 @@ hipError_t grid_build(hipStream_t s, int kind, const double* prims, uint32_t cou
 void launch_gatherTriangles(hipStream_t s, const uint32_t* order, uint32_t total, const double* pos9, const double* nor9,
                             int nsteps, const int* ops, const double* vecs, float pad_w, void* pos_out, void* nor_out);
 void launch_gatherSpheres(hipStream_t s, const uint32_t* order, uint32_t total, const double* sph4, void* out);
+// parseMeshJSON for one (node, mesh) pair: corners de-indexed + transformed into the fp64 soups, bounds6 (fp32 min xyz, max xyz) merged.
+// scratch8: 8 device words (6 encoded bounds, a flag word set to 1 by an out-of-range index, one spare); the caller zeroes word 6 first.
+void launch_meshIngest(hipStream_t s, const double* P, const double* N, const uint32_t* idx, uint32_t n_vertices, uint32_t n_corners,
+                       const float* m16, const float* nm9, double* pos_out, double* nor_out, float* bounds6, uint32_t* scratch8);
 void launch_gatherU32(hipStream_t s, const uint32_t* order, uint32_t total, const uint32_t* in, uint32_t* out);
 
 // ---- single-frame kernels of Assign01 / 04 / 07 (pt_kernels_frame.hip) -----------------------------

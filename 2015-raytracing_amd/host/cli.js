@@ -5,6 +5,7 @@
 //                                                                                   -> RGBA8 frame (+ <out>.radiance.f32) via the N-API addon
 //   node cli.js pack-frame <1|4|7> <mesh.json|mol.pdb|-> <width> <height> [nSlabs]  -> packed inputs of an Assign01/04/07 frame job (stdout)
 //   node cli.js frame      <1|4|7> <mesh.json|-> <width> <height> <nSlabs|0> <out.rgba>  -> RGBA8 frame of that job
+//   node cli.js ingest <mesh.json> <out-prefix> [--device]                          -> parseMeshJSON's arrays (<out>.pos.f64, .nor.f64, .meta.json) by the host or the device
 //   node cli.js devices                                                             -> what webcl.getPlatforms()/getDevices() report
 "use strict";
 const fs = require("fs");
@@ -12,7 +13,7 @@ const path = require("path");
 const scene = require("./scene.js");
 
 function usage() {
-  process.stderr.write(fs.readFileSync(__filename, "utf8").split("\n").slice(1, 10).join("\n") + "\n");
+  process.stderr.write(fs.readFileSync(__filename, "utf8").split("\n").slice(1, 11).join("\n") + "\n");
   process.exit(2);
 }
 
@@ -45,6 +46,26 @@ if (cmd === "pack") {
   const p = frame.packFrame(assign, model, +rest[2], +rest[3], +rest[4] || 2);
   if (cmd === "pack-frame") process.stdout.write(JSON.stringify(scene.packedToJSON(p)));
   else { const px = frame.renderFrame(p); fs.writeFileSync(rest[5], Buffer.from(px.buffer, px.byteOffset, px.byteLength)); }
+} else if (cmd === "ingest") {
+  if (rest.length < 2) usage();
+  const model = JSON.parse(fs.readFileSync(rest[0], "utf8").replace(/^\ufeff/, ""));
+  let pos, nor, meta;
+  if (rest.includes("--device")) {
+    const { webcl } = require("./webcl.js");
+    const ctx = webcl.createContext(webcl.getPlatforms()[0].getDevices(webcl.DEVICE_TYPE_ALL)[0]), q = ctx.createCommandQueue();
+    const r = q.meshIngest(model, scene.normalFromMat4);
+    pos = new Float64Array(r.nTriangles * 9); nor = new Float64Array(r.nTriangles * 9);
+    if (r.nTriangles) { q.enqueueReadBuffer(r.positionsBuf, true, 0, pos.byteLength, pos, []); q.enqueueReadBuffer(r.normalsBuf, true, 0, nor.byteLength, nor, []); }
+    meta = { nTriangles: r.nTriangles, bounds: r.bounds6, materialIndices: r.materialIndices, materials: r.materials };
+    ctx.release();
+  } else {
+    const r = scene.parseMeshJSON(model);
+    pos = new Float64Array(r.positions); nor = new Float64Array(r.normals);
+    meta = { nTriangles: r.nTriangles, bounds: r.bounds.min.concat(r.bounds.max), materialIndices: r.materialIndices, materials: r.materials };
+  }
+  fs.writeFileSync(rest[1] + ".pos.f64", Buffer.from(pos.buffer));
+  fs.writeFileSync(rest[1] + ".nor.f64", Buffer.from(nor.buffer));
+  fs.writeFileSync(rest[1] + ".meta.json", JSON.stringify(meta));
 } else if (cmd === "devices") {
   const { webcl } = require("./webcl.js");
   for (const p of webcl.getPlatforms()) {

@@ -70,10 +70,12 @@ function buildSceneOnDevice(ctx, q, sc, p) {
     g.order.release();
   }
   d.meshes = sc.meshes.map((m, i) => {
-    const pos = new Float64Array(m.jmesh.positions), nor = new Float64Array(m.jmesh.normals);
-    const g = q.gridBuild(1, pos, b6(m.gridBounds), m.nslabs);      // grid on the untransformed mesh (code.js:106-112)
+    const onDev = !!m.jmesh.positionsBuf;   // the soups are already on the device (queue.meshIngest = parseMeshJSON there)
+    const pos = onDev ? m.jmesh.positionsBuf : new Float64Array(m.jmesh.positions), nor = onDev ? m.jmesh.normalsBuf : new Float64Array(m.jmesh.normals);
+    const g = q.gridBuild(1, pos, b6(m.gridBounds), m.nslabs, m.jmesh.nTriangles);      // grid on the untransformed mesh (code.js:106-112)
     const t = q.gridGatherTriangles(g.order, g.total, pos, nor, m.steps, 0);   // normalize / scale / translate in fp64, then fp32
     g.order.release();
+    if (onDev) { pos.release(); nor.release(); m.jmesh.positionsBuf = m.jmesh.normalsBuf = null; }
     return { prims: keep(t.pos), normals: keep(t.nor), cellOffsets: keep(g.offsets), bounds: p.meshes[i].bounds, nSlabs: m.nslabs, meshMatId: m.matId };
   });
   const mat = ctx.createBuffer(webcl.MEM_READ_ONLY, Math.max(p.materials.byteLength, 16));
@@ -86,9 +88,10 @@ class GranularRenderer {
   constructor(packed, opt) {
     opt = opt || {};
     this.p = packed;
-    this.device = pickDevice(opt.device);
+    this.ownCtx = !opt.ctx;
+    this.device = opt.ctx ? opt.ctx.device : pickDevice(opt.device);
     this.useGraph = !!opt.graph;
-    this.ctx = webcl.createContext(this.device);           // createCLBasicResources (code.js:576-608)
+    this.ctx = opt.ctx || webcl.createContext(this.device);           // createCLBasicResources (code.js:576-608)
     this.q = this.ctx.createCommandQueue();
     this.program = this.ctx.createProgram(MANIFEST);
     this.program.build();
@@ -233,7 +236,8 @@ class GranularRenderer {
     Object.values(this.k).forEach((k) => k.release());
     Object.values(this.b).forEach((b) => b.release());
     this.dev.bufs.forEach((b) => b.release());
-    this.program.release(); this.q.release(); this.ctx.release();
+    this.program.release(); this.q.release();
+    if (this.ownCtx) this.ctx.release();
   }
 }
 
@@ -324,11 +328,20 @@ function radianceSums(acu, rpp) {
 
 function renderFile(file, width, height, rpp, passes, opt) {
   opt = opt || {};
-  let packed;
-  if (opt.deviceGrid) {   // host only parses; binning, transforms and fp32 narrowing happen on the device
-    const sc = scene.loadSceneFile(file, width, height, { deferGrids: true });
+  let packed, ownCtx = null;
+  if (opt.deviceGrid) {   // the host only reads the files: mesh ingest (node x mesh transforms, de-indexing: parseMeshJSON), binning, mesh
+                          // transforms and fp32 narrowing all happen on the device
+    ownCtx = webcl.createContext(pickDevice(opt.device));
+    const q = ownCtx.createCommandQueue();
+    const parseMesh = (model) => {
+      const r = q.meshIngest(model, scene.normalFromMat4);
+      const b = r.bounds6.map((v) => (v === Infinity ? Number.MAX_VALUE : v === -Infinity ? -Number.MAX_VALUE : v));   // an empty mesh keeps Bounds' initial values
+      r.bounds = new scene.Bounds(b.slice(0, 3), b.slice(3));
+      return r;
+    };
+    const sc = scene.loadSceneFile(file, width, height, { deferGrids: true, parseMesh: opt.hostIngest ? undefined : parseMesh });
     packed = scene.packScene(sc, width, height, rpp, 1, true);
-    opt = Object.assign({}, opt, { sceneObject: sc });
+    opt = Object.assign({}, opt, { sceneObject: sc, ctx: ownCtx });
   } else packed = scene.packScene(scene.loadSceneFile(file, width, height), width, height, rpp);
   if (opt.gpus) return renderTiled(packed, opt.gpus, passes, opt);
   const R = opt.granular ? new GranularRenderer(packed, opt) : new FusedRenderer(packed, opt);
@@ -338,6 +351,7 @@ function renderFile(file, width, height, rpp, passes, opt) {
   const res = { pixel: R.readPixels(), radiance: opt.granular ? radianceSums(R.readAcu(), rpp) : R.readRadiance(), ms: ms,
                 device: R.device.getInfo(webcl.DEVICE_NAME) };
   R.release();
+  if (ownCtx) ownCtx.release();
   return res;
 }
 

@@ -389,7 +389,9 @@ function loadScene(xmlText, width, height, readFile, opt) {
 
   const sceneBounds = new Bounds();
   const meshes = byTag(doc, "mesh").map((e) => {
-    const jm = parseMeshJSON(JSON.parse(readFile(xmlStr(e, "file"))));
+    // opt.parseMesh: the device ingest of the renderer (queue.meshIngest) in place of the host's parseMeshJSON; it returns the same
+    // record with device soups (positionsBuf / normalsBuf) instead of the positions / normals arrays
+    const jm = (opt && opt.parseMesh ? opt.parseMesh : parseMeshJSON)(JSON.parse(readFile(xmlStr(e, "file"))));
     const mesh = new Mesh(jm, xmlNum(e, "nslabs"), lookup[xmlStr(e, "matId")], deferGrid);
     if (xmlStr(e, "normalize") == "yes") mesh.normalize();
     mesh.scale(xmlVec3(e, "scale"));
@@ -455,5 +457,5 @@ function packedToJSON(p) {
   return o;
 }
 
-module.exports = { Bounds, Camera, Light, Mesh, parseXML, parseMeshJSON, loadScene, loadSceneFile, splitSphereData, splitTriangleData,
+module.exports = { Bounds, Camera, Light, Mesh, parseXML, parseMeshJSON, normalFromMat4, loadScene, loadSceneFile, splitSphereData, splitTriangleData,
                    splitMaterialData, bounds2AABB, buildGrid, packScene, packedToJSON };

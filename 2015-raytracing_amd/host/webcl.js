@@ -168,21 +168,24 @@ class WebCLCommandQueue {
     wrap(() => native().renderPass(this.ctx.h, d));
   }
   // ---- extension: the host's grid builders on the device (mirt_grid_build / mirt_grid_gather_*) ----
-  gridBuild(kind, primsF64, bounds6, nSlabs) {
-    const count = primsF64.length / (kind ? 9 : 4);
-    let pb = null;
-    if (count) { pb = this.ctx.createBuffer(C.MEM_READ_WRITE, primsF64.byteLength); this.enqueueWriteBuffer(pb, false, 0, primsF64.byteLength, primsF64, []); }
-    const r = wrap(() => native().gridBuild(this.ctx.h, kind, pb ? pb.h : null, count, nSlabs, new Float64Array(bounds6)));
-    if (pb) pb.release();
+  // primsF64: a Float64Array (uploaded here) or a WebCLBuffer that already holds the fp64 soup (meshIngest) with `count` primitives
+  gridBuild(kind, primsF64, bounds6, nSlabs, count) {
+    const onDevice = primsF64 instanceof WebCLBuffer;
+    if (!onDevice) count = primsF64.length / (kind ? 9 : 4);
+    let pb = onDevice ? primsF64 : null;
+    if (!onDevice && count) { pb = this.ctx.createBuffer(C.MEM_READ_WRITE, primsF64.byteLength); this.enqueueWriteBuffer(pb, false, 0, primsF64.byteLength, primsF64, []); }
+    const r = wrap(() => native().gridBuild(this.ctx.h, kind, pb && count ? pb.h : null, count, nSlabs, new Float64Array(bounds6)));
+    if (pb && !onDevice) pb.release();
     return { offsets: new WebCLBuffer(this.ctx, (nSlabs * nSlabs * nSlabs + 1) * 4, 0, r.offsets), order: new WebCLBuffer(this.ctx, Math.max(r.total * 4, 16), 0, r.order), total: r.total };
   }
   gridGatherTriangles(order, total, posF64, norF64, steps, padW) {
-    const up = (a) => { const b = this.ctx.createBuffer(C.MEM_READ_WRITE, Math.max(a.byteLength, 16)); if (a.byteLength) this.enqueueWriteBuffer(b, false, 0, a.byteLength, a, []); return b; };
+    const onDevice = posF64 instanceof WebCLBuffer;   // fp64 soups already on the device (meshIngest): used in place, left to the caller
+    const up = (a) => { if (onDevice) return a; const b = this.ctx.createBuffer(C.MEM_READ_WRITE, Math.max(a.byteLength, 16)); if (a.byteLength) this.enqueueWriteBuffer(b, false, 0, a.byteLength, a, []); return b; };
     const pb = up(posF64), nb = norF64 ? up(norF64) : null;
     const ops = new Int32Array(steps.map((s) => s.op)), vecs = new Float64Array(steps.length * 3);
     steps.forEach((s, i) => vecs.set(s.v, 3 * i));
     const r = wrap(() => native().gridGatherTriangles(this.ctx.h, order.h, total, pb.h, nb ? nb.h : null, ops, vecs, padW || 0));
-    pb.release(); if (nb) nb.release();
+    if (!onDevice) { pb.release(); if (nb) nb.release(); }
     return { pos: new WebCLBuffer(this.ctx, Math.max(total * 48, 16), 0, r.pos), nor: r.nor ? new WebCLBuffer(this.ctx, Math.max(total * 48, 16), 0, r.nor) : null };
   }
   gridGatherSpheres(order, total, sphF64) {
@@ -198,6 +201,47 @@ class WebCLCommandQueue {
     const h = wrap(() => native().gridGatherU32(this.ctx.h, order.h, total, b.h));
     b.release();
     return new WebCLBuffer(this.ctx, Math.max(total * 4, 16), 0, h);
+  }
+  // ---- extension: parseMeshJSON (tri/meshDataVersion1.js:12-78) on the device (mirt_mesh_ingest).  `model` is the parsed mesh file;
+  // `normalFromMat4` the host's per-node 3x3 (scene.js).  Every mesh's vertex arrays go up once; each (node, mesh) pair is one launch
+  // set.  Returns the fp64 soups as device buffers (feed them to gridBuild / gridGatherTriangles), the bounds and the small host arrays.
+  meshIngest(model, normalFromMat4) {
+    const nNodes = model.nodes ? model.nodes.length : 1;
+    const cornersOf = (mesh) => (mesh.indices ? mesh.indices.length : mesh.vertexPositions.length / 3);
+    let nCorners = 0;
+    for (let k = 0; k < nNodes; k++) {
+      const ids = model.nodes ? model.nodes[k].meshIndices : model.meshes.map((_, i) => i);
+      for (const i of ids) nCorners += cornersOf(model.meshes[i]);
+    }
+    const mk = (bytes) => this.ctx.createBuffer(C.MEM_READ_WRITE, Math.max(bytes, 16));
+    const up = (ta) => { const b = mk(ta.byteLength); if (ta.byteLength) this.enqueueWriteBuffer(b, false, 0, ta.byteLength, ta, []); return b; };
+    const pos = mk(nCorners * 24), nor = mk(nCorners * 24);
+    const bounds = up(new Float32Array([Infinity, Infinity, Infinity, -Infinity, -Infinity, -Infinity]));
+    const uploaded = new Map();   // mesh index -> its three device arrays
+    const matIdx = [];
+    let first = 0;
+    for (let k = 0; k < nNodes; k++) {
+      const m = new Float32Array(16);   // mat4.create() + mat4.copy(): the matrix narrowed to fp32
+      if (model.nodes) m.set(model.nodes[k].modelMatrix); else { m[0] = m[5] = m[10] = m[15] = 1; }
+      const nm = normalFromMat4(m);
+      const ids = model.nodes ? model.nodes[k].meshIndices : model.meshes.map((_, i) => i);
+      for (const i of ids) {
+        const mesh = model.meshes[i];
+        if (!uploaded.has(i)) uploaded.set(i, { p: up(new Float64Array(mesh.vertexPositions)), n: up(new Float64Array(mesh.vertexNormals)), idx: mesh.indices ? up(new Uint32Array(mesh.indices)) : null });
+        const u = uploaded.get(i), nc = cornersOf(mesh);
+        wrap(() => native().meshIngest(this.ctx.h, { nVertices: mesh.vertexPositions.length / 3, nCorners: nc, firstCorner: first, model: m, normalMat: nm,
+                                                       positions: u.p.h, normals: u.n.h, indices: u.idx ? u.idx.h : undefined }, pos.h, nor.h, bounds.h));
+        for (let t = 0; t < nc / 3; t++) matIdx.push(mesh.materialIndex);
+        first += nc;
+      }
+    }
+    const b6 = new Float32Array(6);
+    this.enqueueReadBuffer(bounds, true, 0, 24, b6, []);
+    uploaded.forEach((u) => { u.p.release(); u.n.release(); if (u.idx) u.idx.release(); });
+    bounds.release();
+    const materials = [];
+    (model.materials || []).forEach((mat) => { for (let c = 0; c < 4; c++) materials.push(mat.diffuseReflectance[c]); });
+    return { nTriangles: nCorners / 3, positionsBuf: pos, normalsBuf: nor, bounds6: Array.from(b6), materialIndices: matIdx, materials: materials, nMaterials: materials.length / 4 };
   }
   seedFill(buf, firstRay, count, seedBase) { wrap(() => native().seedFill(this.ctx.h, buf.h, firstRay, count, seedBase || 0)); }
   zero(buf) { wrap(() => native().zero(this.ctx.h, buf.h)); }

@@ -34,6 +34,12 @@ class _GridBuildDesc(C.Structure):
                 ("bounds", C.c_double * 6), ("prims_f64", C.c_void_p)]
 
 
+class _MeshIngestDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_vertices", C.c_uint32), ("n_corners", C.c_uint32), ("first_corner", C.c_uint32),
+                ("model", C.c_float * 16), ("normal_mat", C.c_float * 9), ("positions_f64", C.c_void_p), ("normals_f64", C.c_void_p),
+                ("indices_u32", C.c_void_p)]
+
+
 class _Light(C.Structure):
     _fields_ = [("shadow", C.c_float * 16), ("scene", C.c_float * 16), ("light", C.c_float * 16)]
 
@@ -98,6 +104,7 @@ SYMBOLS = {
     "mirt_graph_release": (C.c_int, [C.c_void_p]),
     "mirt_debug_numerics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mirt_buf_invalidate": (C.c_int, [C.c_void_p]),
+    "mirt_mesh_ingest": (C.c_int, [C.c_void_p, C.POINTER(_MeshIngestDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mirt_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "mirt_group_size": (C.c_int, [C.c_void_p]),
     "mirt_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),

@@ -205,6 +205,26 @@ typedef struct mirt_grid_build_desc {
     double bounds[6];       /* min x,y,z, max x,y,z of the set (Bounds, lib/utilities.js:389-422) */
     mirt_buf* prims_f64;    /* device buffer of doubles, uploaded with mirt_buf_write */
 } mirt_grid_build_desc;
+/* ---- mesh ingest on the device: parseMeshJSON (A10 tri/meshDataVersion1.js:12-78) for one (node, mesh) pair of an Assimp-style mesh
+ * file: every triangle corner de-indexed, its position through the node's model matrix (gl-matrix vec3.transformMat4 on Float32Array
+ * operands: fp32 matrix, double sums, fp32 store) and its normal through the normal matrix (vec3.transformMat3), written as the fp64
+ * soups mirt_grid_build / mirt_grid_gather_triangles consume, at corner offset `first_corner`; `bounds6` (6 floats: min xyz, max xyz,
+ * initialise to +inf / -inf) is merged with the mesh's TRANSFORMED vertices, all of them (:33-37).  The normal matrix
+ * (mat3.normalFromMat4 of the model matrix, nine floats) is per node and computed by the caller.  Synchronises (an index past the
+ * vertex array is MIRT_E_DATA).  Bit-identical to the reference host's arrays (tests/test_js_host.py, device vs host ingest). */
+typedef struct mirt_mesh_ingest_desc {
+    uint32_t struct_size;
+    uint32_t n_vertices;        /* entries of positions / normals (3 doubles each) */
+    uint32_t n_corners;         /* 3 x triangles of this mesh: indices.length, or n_vertices when un-indexed */
+    uint32_t first_corner;      /* where this (node, mesh) pair's corners start in the output soups */
+    float model[16];            /* node.modelMatrix narrowed to fp32 (mat4.copy into a Float32Array), column-major */
+    float normal_mat[9];        /* mat3.normalFromMat4(model) */
+    mirt_buf* positions_f64;    /* mesh.vertexPositions */
+    mirt_buf* normals_f64;      /* mesh.vertexNormals */
+    mirt_buf* indices_u32;      /* mesh.indices, or NULL */
+} mirt_mesh_ingest_desc;
+MIRT_API int mirt_mesh_ingest(mirt_ctx* ctx, const mirt_mesh_ingest_desc* d, mirt_buf* pos9_out, mirt_buf* nor9_out, mirt_buf* bounds6);
+
 /* cell_offsets: uint[n^3+1]; order: uint[total], order[slot] = input index of the primitive in that slot */
 MIRT_API int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cell_offsets, mirt_buf** order, uint32_t* total);
 /* slot arrays from `order`.  Triangles: 3 x float4 per slot (w = pad_w: 0 in A07/A10, 1 for A04's positions), after up to four

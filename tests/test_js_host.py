@@ -132,7 +132,8 @@ def test_webcl_surface_without_a_gpu():
 @pytest.mark.parametrize("name", sorted(OWN_SCENES))
 def test_node_render_matches_compiled_reference(tmp_path, name, mode):
     """scene.xml -> JS host -> N-API addon -> C ABI -> HIP kernels -> frame, against the compiled reference's frame.
-    `device-grid`: the host only parses; binning, mesh transforms and fp32 narrowing run on the device (mirt_grid_build)."""
+    `device-grid`: the host only reads the files; mesh ingest (mirt_mesh_ingest), binning, mesh transforms and fp32 narrowing run on the
+    device (mirt_grid_build / mirt_grid_gather_*)."""
     fx, sc = load_fixture(name)
     scene, w, h, rpp = OWN_SCENES[name]
     out = str(tmp_path / "frame.rgba")
@@ -166,6 +167,34 @@ def test_node_tile_arithmetic_matches_python():
         want = tiling.row_tiles(h, n)
         assert [tuple(x) for x in t if x[1]] == [w for w in want if w[1]]
         assert sum(x[1] for x in t) == h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh", ["icosphere.json", "octahedra.json", "terrain.json"])
+def test_device_mesh_ingest_equals_host_parse(tmp_path, mesh):
+    """parseMeshJSON (tri/meshDataVersion1.js:12-78) on the device (mirt_mesh_ingest: node x mesh transforms through the fp32 matrices in
+    double, de-indexing, bounds over all vertices) == the JavaScript host's, whose packed scenes equal the reference host's: positions,
+    normals (fp64 arrays of fp32-valued entries), bounds, material indices.  Meshes: one rotated + scaled + translated node, two nodes
+    sharing a vertex array, an un-indexed mesh without nodes."""
+    path = os.path.join(PAGE, "tri", mesh)
+    h, d = str(tmp_path / "h"), str(tmp_path / "d")
+    run_node(os.path.join(HOST, "cli.js"), "ingest", path, h)
+    run_node(os.path.join(HOST, "cli.js"), "ingest", path, d, "--device")
+    for ext in (".pos.f64", ".nor.f64"):
+        a, b = np.fromfile(h + ext, np.uint64), np.fromfile(d + ext, np.uint64)
+        assert a.size and np.array_equal(a, b), ext
+    mh, md = json.load(open(h + ".meta.json")), json.load(open(d + ".meta.json"))
+    assert mh == md
+
+
+@pytest.mark.gpu
+def test_device_mesh_ingest_rejects_a_bad_index(tmp_path):
+    bad = {"meshes": [{"vertexPositions": [0, 0, 0, 1, 0, 0, 0, 1, 0], "vertexNormals": [0, 0, 1] * 3, "indices": [0, 1, 7], "materialIndex": 0}],
+           "materials": [{"diffuseReflectance": [1, 1, 1, 1]}]}
+    f = str(tmp_path / "bad.json")
+    json.dump(bad, open(f, "w"))
+    r = subprocess.run([node, os.path.join(HOST, "cli.js"), "ingest", f, str(tmp_path / "o"), "--device"], capture_output=True)
+    assert r.returncode != 0 and b"refers past the 3 vertices" in r.stderr
 
 
 @pytest.mark.gpu
