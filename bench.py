@@ -77,6 +77,46 @@ def cpu_baseline(packed_json, log, bounces, rpp=256):
             "note": "the CPU checker models v_rsq_f32 / v_sqrt_f32 through 2 x 16 MB measured tables (oracle/cl_numerics.h): bit-exact, cache-unfriendly"}
 
 
+def reference_gpu_baseline(packed_json, log, bounces):
+    """The same baseline leg, second half: the REFERENCE'S OWN kernels -- its code.cl as AMD's OpenCL toolchain compiles it for gfx950
+    (oracle/_ref/a10_gfx950.hsaco, a checker; present where the build container's tree travelled) -- driven through executeRender's
+    launch sequence on this very GPU (oracle/ref_gpu.py), on a bounded sample: the frame at 16 rays per pixel.  What the reference itself
+    achieves on an MI355X, beside `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import a10_pass as A
+    import ref_gpu as G
+    if not G.available():
+        return None
+    d = json.loads(packed_json)
+    d.update(rays_per_pixel=16)
+    sc = A.Scene(d)
+    n, npix = sc.total_rays, sc.width * sc.height
+    k = G.GpuRefKernels()
+
+    class St:
+        pass
+    st = St()
+    st.rays, st.pois, st.shadow = G.DevBuf(n * 48), G.DevBuf(n * 64), G.DevBuf(n * 48)
+    st.acu, st.seeds, st.pixel = G.DevBuf(n * 16), G.DevBuf(n * 4), G.DevBuf(npix * 4)
+    st.passes = 1
+    st.seeds.upload(A.make_seeds(n))
+    A.run_pass(k, sc, st, bounces=bounces)
+    G.chk(G.hip().hipDeviceSynchronize(), "sync")
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        A.run_pass(k, sc, st, bounces=bounces, init_acu=False)
+    G.chk(G.hip().hipDeviceSynchronize(), "sync")
+    dt = (time.perf_counter() - t0) / reps
+    for b in (st.rays, st.pois, st.shadow, st.acu, st.seeds, st.pixel):
+        b.free()
+    k.release()
+    log(f"reference_gpu_baseline: {n} samples in {dt * 1e3:.1f} ms per pass")
+    return {"value": round(n / dt / 1e6, 1), "unit": "Msamples/s", "kind": "reference", "where": "this MI355X",
+            "what": "the reference's code.cl compiled by AMD's OpenCL toolchain for gfx950, its 14 kernels launched in executeRender's order",
+            "sample": f"the same scene at {sc.width}x{sc.height} rpp16 1 pass {bounces} bounces ({n} samples, {dt * 1e3:.1f} ms per pass)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +265,13 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(packed, log, args.bounces, sc.rpp)
+        try:
+            rg = reference_gpu_baseline(packed, log, args.bounces)
+        except Exception as e:   # a baseline, never a reason to lose the bench line
+            log(f"reference_gpu_baseline skipped: {e}")
+            rg = None
+        if rg:
+            out["reference_gpu_baseline"] = rg
     if rank == 0 and world == 1 and args.bounces == 8 and not args.no_depth5 and fps_table:
         # the reference's own depth (five bounces), same frame, two untimed-warmup-free steps: reported beside the headline
         t5 = []

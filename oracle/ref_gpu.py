@@ -56,12 +56,40 @@ def hip():
     if _hip is None:
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipGetErrorString.restype = C.c_char_p
+        _hip.hipMalloc.argtypes = [C.c_void_p, C.c_size_t]                      # sizes beyond 2^31: never leave them to ctypes' int default
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipFree.argtypes = [C.c_void_p]
     return _hip
 
 
 def chk(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what}: {hip().hipGetErrorString(rc).decode()}")
+
+
+class DevBuf:
+    """device-only memory for runs too large to mirror on the host (the full headline frame: ~95 GB of rays, vertices, shadow rays)"""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        chk(hip().hipMalloc(C.byref(p), max(self.nbytes, 16)), f"hipMalloc({self.nbytes})")
+        self.ptr = p.value
+
+    def upload(self, a):
+        assert a.nbytes <= self.nbytes and a.flags["C_CONTIGUOUS"]
+        chk(hip().hipMemcpy(C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1), "hipMemcpy H2D")
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype)
+        assert out.nbytes <= self.nbytes
+        chk(hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), out.nbytes, 2), "hipMemcpy D2H")
+        return out
+
+    def free(self):
+        if self.ptr:
+            hip().hipFree(C.c_void_p(self.ptr))
+            self.ptr = 0
 
 
 class GpuModule:
@@ -86,6 +114,8 @@ class GpuModule:
     # ---- buffers
     def buf(self, a):
         """device mirror of a numpy array (uploaded when first seen); returns the device pointer as an int"""
+        if isinstance(a, DevBuf):
+            return a.ptr
         m = self.mirrors.get(id(a))
         if m is None:
             assert a.flags["C_CONTIGUOUS"]

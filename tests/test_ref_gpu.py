@@ -155,6 +155,52 @@ def test_reference_binary_on_the_device_equals_the_fixtures(name):
         assert_state_equal(name + " final", st.snapshot(), fx, "f")
 
 
+@pytest.mark.gpu
+@needs_gpu_ref
+def test_headline_frame_equals_the_reference_binary(pkg):
+    """BASELINE's headline frame at FULL size -- cornell.xml 1920x1080 x 256 rays per pixel, depth 8: 530 841 600 samples -- rendered by
+    the reference's own kernels (AMD OpenCL build) on the MI355X, 66 launches over 95 GB of rays / vertices / shadow rays that never leave
+    the device, and by mirt_render_pass: every accumulator, every seed and every pixel equal, bit for bit."""
+    from raytracing_amd.pyhost import mirt, render, scene
+    base = scene.PackedScene(open(os.path.join(ROOT, "tests", "golden", "scene_cornell_1920x1080_r256.json")).read())
+    sc = A.Scene(base.d)
+    n, npix = sc.total_rays, sc.width * sc.height
+    assert n == 530841600
+    ctx = mirt.Context(0)
+    fr = render.FusedRenderer(ctx, base, want_radiance=False)           # seeds generated on the device (the closed form of make_seeds)
+    seeds = fr.seeds.read(np.int32)
+    fr.execute_render(bounces=8, fresh=True)
+    ctx.finish()
+
+    k = G.GpuRefKernels()
+
+    class St:
+        pass
+    st = St()
+    st.rays, st.pois, st.shadow = G.DevBuf(n * 48), G.DevBuf(n * 64), G.DevBuf(n * 48)
+    st.acu, st.seeds, st.pixel = G.DevBuf(n * 16), G.DevBuf(n * 4), G.DevBuf(npix * 4)
+    st.passes = 1
+    st.seeds.upload(seeds)
+    del seeds
+    A.run_pass(k, sc, st, bounces=8)
+    try:
+        assert np.array_equal(st.pixel.download(np.uint8, npix * 4), fr.pixel.read(np.uint8)), "pixels"
+        assert np.array_equal(st.seeds.download(np.int32, n), fr.seeds.read(np.int32)), "seeds"
+        chunk = 1 << 26                                                # 64 M floats at a time: 8.5 GB of accumulators
+        for off in range(0, 4 * n, chunk):
+            m = min(chunk, 4 * n - off)
+            want = np.empty(m, np.float32)
+            G.chk(G.hip().hipMemcpy(want.ctypes.data_as(C.c_void_p), C.c_void_p(st.acu.ptr + 4 * off), 4 * m, 2), "D2H")
+            got = fr.acu.read(np.float32, count=m, offset=4 * off)
+            assert np.array_equal(canon(got), canon(want)), f"accumulators differ in floats [{off}, {off + m})"
+    finally:
+        for b in (st.rays, st.pois, st.shadow, st.acu, st.seeds, st.pixel):
+            b.free()
+        k.release()
+        fr.release()
+        ctx.destroy()
+
+
 # ---------------------------------------------------------------- CPU ----------------------------------------------------------------
 
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
