@@ -193,7 +193,8 @@ __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16
         if (!alive) break;
         float ti, b, g;
         const float4* __restrict__ p = prep + 3u * (size_t)i;
-        const bool hit = tri_test<TRI_A07, false>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, g);
+        // adjacent pixels walk the same cells in nearly the same order: staged rejection with wave ballots (tri_test_staged)
+        const bool hit = tri_test_staged<TRI_A07>(true, ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, g);
         if (hit && ti < champ_t) { champ_t = ti; champ_i = i; cb = b; cg = g; hx = ax.slab; hy = ay.slab; hz = az.slab; }
         ++i;
     }

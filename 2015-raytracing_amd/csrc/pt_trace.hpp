@@ -56,6 +56,37 @@ PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const f
     return ok != 0;
 }
 
+// The same test, STAGED, for loops where every active lane holds a (possibly different) triangle and most lanes are rejected early
+// (the frame kernels of Assign04 / 07: adjacent pixels against small triangles): after each of the reference's early-outs a wave ballot
+// asks whether ANY lane is still in; if none is, the rest is skipped for the whole wave.  Lanes that are still in compute exactly the values
+// the straight-line test computes (1 / div through the guarded refined reciprocal, bit-identical to the division: pt_numerics.hpp).
+// `active`: lanes that hold a triangle at all.
+template <int RULE>
+PT_DEV bool tri_test_staged(bool active, f3 o, f3 d, float cmin, float cmax, const float4 A, const float4 B, const float4 C,
+                            float& t_out, float& beta_out, float& gamma_out) {
+    const f3 p0 = mk3(A.x, A.y, A.z), e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z), n = mk3(A.w, B.w, C.w);
+    const float div = dot3(n, d);
+    bool in = active & !(div <= 0);
+    if (__builtin_amdgcn_ballot_w64(in) == 0ull) return false;
+    const float idiv = rcp_exact(div, !in);
+    const f3 s = sub3(o, p0);
+    const float beta = dot3(cross3(s, d), e2) * idiv;
+    in = in & !(beta < 0.0f) & !(beta > 1.0f);
+    if (__builtin_amdgcn_ballot_w64(in) == 0ull) return false;
+    const float gamma = dot3(cross3(s, e1), d) * idiv;
+    const float gb = gamma + beta;
+    if (RULE == TRI_A04) in = in & !(gamma < 0.0f) & !(gamma > 1.0f) & !(gb < 0.0f) & !(gb > 1.0f);
+    else in = in & !(gamma < 0.0f) & !(gb < 0.0f) & !(gb > 1.0f);
+    if (__builtin_amdgcn_ballot_w64(in) == 0ull) return false;
+    const float t = dot3(cross3(s, e2), e1) * -idiv;
+    if (RULE == TRI_A10) in = in & (t >= cmin) & (t <= cmax);
+    else in = in & (t > cmin) & (t < cmax);
+    t_out = t;
+    beta_out = beta;
+    gamma_out = gamma;
+    return in;
+}
+
 // Ray-side guard of the exact cheap divisions (pt_numerics.hpp "exact division, cheaper"): |d_k| in [2^-40, 2^40] and o_k zero or
 // in [2^-30, 2^20].  With the geometry-side guard (GridArgs::fast_ok, checked on the host: bounds zero or in [2^-30, 2^20],
 // triangle-plane normals zero or in [2^-40, 2^40] per component) it gives
