@@ -90,3 +90,44 @@ def run_frame(kind, fr):
         f = getattr(lib, pre + "meshTrace"); f.argtypes = [vp, fp, vp, u, vp, vp, vp, vp, fp, u, vp, sz, sz]; f.restype = None
         f(_p(pixels), cp, _p(rays), fr.t_size, _p(fr.pos), _p(fr.normal), _p(fr.mindex), _p(fr.mcolor), bp, fr.n_slabs, _p(fr.slab_size), gx, gy)
     return pixels, rays
+
+
+# ---- the same jobs on the reference binaries for the MI355X (oracle/_ref/a0N_gfx950.hsaco, oracle/ref_gpu.py) ------------------------
+FRAME_KERNEL_ARGS = {   # argument kinds in the kernels' own order: B buffer, U uint, V float16, X AABB
+    1: {"raytrace": "BV"},                                                          # A01 code.cl:116
+    4: {"initTrace": "BVB", "meshTrace": "BVBUBBBB"},                               # A04 code.cl:204, 262
+    7: {"initTrace": "BVBX", "meshTrace": "BVBUBBBBXUB", "molTrace": "BVBUBBBXUB"},  # A07 code.cl:311, 475, 337
+}
+
+
+def run_frame_gpu(fr, device=0):
+    """run_frame on the reference's own kernels as AMD's OpenCL toolchain builds them, on the device.  Same launch shapes as the reference
+    host: 2-D NDRange, local [8, 8], globals padded (A01: exactly cols x rows, its kernel has no range check)."""
+    import ref_gpu as G
+    mod = G.GpuModule(os.path.join(HERE, "_ref", f"a{fr.assign:02d}_gfx950.hsaco"), FRAME_KERNEL_ARGS[fr.assign], device)
+    w, h = fr.width, fr.height
+    g = [A._ceil(w, 8), A._ceil(h, 8)]
+    pixels = np.zeros((w * h, 4), np.uint8)
+    cam = np.ascontiguousarray(fr.cam, np.float32).tobytes()
+    B = mod.buf
+    try:
+        if fr.assign == 1:
+            assert w % 8 == 0 and h % 8 == 0
+            mod.launch("raytrace", [B(pixels), cam], [w, h], [8, 8])
+            mod.flush()
+            return pixels, None
+        rays = np.zeros(w * h, A.RAY_DT)
+        if fr.assign == 4:
+            mod.launch("initTrace", [B(pixels), cam, B(rays)], g, [8, 8])
+            mod.launch("meshTrace", [B(pixels), cam, B(rays), fr.t_size, B(fr.pos), B(fr.normal), B(fr.mindex), B(fr.mcolor)], g, [8, 8])
+        else:
+            bound = np.ascontiguousarray(fr.bounds, np.float32).tobytes()
+            mod.launch("initTrace", [B(pixels), cam, B(rays), bound], g, [8, 8])
+            if fr.mol:
+                mod.launch("molTrace", [B(pixels), cam, B(rays), fr.s_size, B(fr.atoms), B(fr.mindex), B(fr.mcolor), bound, fr.n_slabs, B(fr.slab_size)], g, [8, 8])
+            else:
+                mod.launch("meshTrace", [B(pixels), cam, B(rays), fr.t_size, B(fr.pos), B(fr.normal), B(fr.mindex), B(fr.mcolor), bound, fr.n_slabs, B(fr.slab_size)], g, [8, 8])
+        mod.flush()
+        return pixels, rays
+    finally:
+        mod.release()

@@ -12,7 +12,7 @@ import pytest
 
 import a10_pass as A
 import frame_pass as F
-from conftest import GOLDEN, HOST, PAGE, bits
+from conftest import GOLDEN, HOST, PAGE, ROOT, bits
 
 CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "frame_*.npz")))
 node = shutil.which("node")
@@ -192,3 +192,25 @@ def _full_size(ctx, name, size):
     want, _ = F.run_frame("oracle", F.Frame(d))
     assert np.array_equal(px, want)
     print(f"\n{name} at {size[0]}x{size[1]}: {ms:.2f} ms incl. uploads")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "a07_gfx950.hsaco")), reason="oracle/_ref/*.hsaco not built (make -C oracle ref_gpu, build container)")
+@pytest.mark.parametrize("name,size", [("frame_a01_512x512", None), ("frame_a04_parliament_96x64", (1024, 1024)), ("frame_a04_teapot_160x120", (1024, 1024)),
+                                       ("frame_a07_parliament_n16_160x120", (1920, 1080)), ("frame_a07_teapot_n2_160x120", (1920, 1080)),
+                                       ("frame_a07_mol_3IZ4_n16_96x64", (1920, 1080)), ("frame_a07_mol_c60_n4_160x120", (1920, 1080)),
+                                       ("frame_a07_own_terrain_n5_96x64", (1920, 1080))])
+def test_full_size_frames_equal_the_reference_binaries(ctx, pkg, name, size):
+    """BASELINE configs 1-3 (and the molecule mode) at full size against the REFERENCE'S OWN kernels: Assign01 / 04 / 07 code.cl as AMD's
+    OpenCL toolchain builds them for gfx950, run on the device (oracle/frame_pass.run_frame_gpu): every pixel, and every ray's maxt."""
+    from raytracing_amd.pyhost import render
+    fx, d = fixture(name)
+    if size:
+        d = resized(d, *size)
+    want_px, want_rays = F.run_frame_gpu(F.Frame(d))
+    px, rays = render.render_frame(ctx, render.FramePacked(d))
+    assert np.array_equal(px, want_px)
+    if want_rays is not None and rays is not None:
+        got = np.ascontiguousarray(rays).view(A.RAY_DT)
+        assert np.array_equal(bits(got["maxt"]), bits(want_rays["maxt"]))
+    assert (px[:, :3].max(axis=1) > 0).mean() > 0.02

@@ -157,6 +157,36 @@ def test_reference_binary_on_the_device_equals_the_fixtures(name):
 
 @pytest.mark.gpu
 @needs_gpu_ref
+@pytest.mark.parametrize("name", ["basic_32x24_r4", "cornell_32x24_r4", "triangles_32x24_r4", "twoLights_32x24_r4", "threeLights_32x24_r1",
+                                  "cornell_official_64x48_r1", "cornell_teapot3_32x24_r4", "own_flat_32x24_r4", "own_gems_48x36_r4", "own_studio_48x36_r4"])
+def test_every_scene_equals_the_reference_binary_at_depth_8(pkg, name):
+    """Every scene the fixtures carry (the reference's A10 scenes incl. the grid-mesh ones, and ours) at 480x270 x 16 rays per pixel,
+    depth 8, two progressive passes (2.07 M samples each): mirt_render_pass against the reference binary on the device, same seeds --
+    every accumulator, seed and pixel."""
+    from raytracing_amd.pyhost import mirt, render, scene
+    fx, sc0 = load_fixture(name)
+    ps = scene.PackedScene(dict(sc0.d)).resized(480, 270, 16)
+    sc = A.Scene(ps.d)
+    seeds = A.make_seeds(sc.total_rays, seed_base=11)
+    k = G.GpuRefKernels()
+    st = A.PassState(sc, seeds)
+    ctx = mirt.Context(0)
+    fr = render.FusedRenderer(ctx, ps, seeds=seeds)
+    try:
+        for p in range(2):
+            A.run_pass(k, sc, st, bounces=8, init_acu=(p == 0))
+            fr.execute_render(bounces=8)
+        assert np.array_equal(canon(fr.acu.read(np.float32).reshape(-1, 4)), canon(st.acu)), "accumulators"
+        assert np.array_equal(fr.seeds.read(np.int32), st.seeds), "seeds"
+        assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), st.pixel), "pixels"
+    finally:
+        k.release()
+        fr.release()
+        ctx.destroy()
+
+
+@pytest.mark.gpu
+@needs_gpu_ref
 def test_headline_frame_equals_the_reference_binary(pkg):
     """BASELINE's headline frame at FULL size -- cornell.xml 1920x1080 x 256 rays per pixel, depth 8: 530 841 600 samples -- rendered by
     the reference's own kernels (AMD OpenCL build) on the MI355X, 66 launches over 95 GB of rays / vertices / shadow rays that never leave
