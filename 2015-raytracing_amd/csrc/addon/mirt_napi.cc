@@ -140,6 +140,23 @@ napi_value Finish(napi_env env, napi_callback_info info) {
     if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
     return undef(env);
 }
+napi_value CtxSetFusion(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    void* c; uint32_t level;
+    if (!get_ext(env, argv[0], &c) || !get_u32(env, argv[1], &level)) return throw_type(env, "ctxSetFusion(ctx, level)");
+    int rc = mirt_ctx_set_fusion((mirt_ctx*)c, (int)level);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    return undef(env);
+}
+napi_value CtxFusedPasses(napi_env env, napi_callback_info info) {
+    ARGS(1);
+    void* c;
+    if (!get_ext(env, argv[0], &c)) return throw_type(env, "ctxFusedPasses(ctx)");
+    uint64_t n = 0;
+    int rc = mirt_ctx_fused_passes((mirt_ctx*)c, &n);
+    if (rc) return throw_mirt(env, rc, (mirt_ctx*)c);
+    return mk_num(env, (double)n);
+}
 napi_value BufCreate(napi_env env, napi_callback_info info) {
     ARGS(3);
     void* c; double bytes; uint32_t flags;
@@ -559,7 +576,7 @@ napi_value Gather(napi_env env, napi_callback_info info) {
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"deviceCount", DeviceCount}, {"deviceName", DeviceName}, {"version", Version},
-        {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"finish", Finish},
+        {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"finish", Finish}, {"ctxSetFusion", CtxSetFusion}, {"ctxFusedPasses", CtxFusedPasses},
         {"bufCreate", BufCreate}, {"bufRelease", BufRelease}, {"bufSize", BufSize}, {"bufWrite", BufWrite}, {"bufRead", BufRead},
         {"programCheck", ProgramCheck}, {"programDialect", ProgramDialect}, {"kernelGet", KernelGet}, {"kernelRelease", KernelRelease}, {"kernelNumArgs", KernelNumArgs},
         {"kernelPreferredMultiple", KernelPreferredMultiple}, {"kernelSetArg", KernelSetArg}, {"enqueue", Enqueue},

@@ -52,6 +52,22 @@ bool live_is(const void* p, HandleKind k) {
 struct mirt_graph;
 struct mirt_group;
 
+struct mirt_buf;
+enum ArgType { A_BUF, A_U32, A_F32, A_F16, A_AABB };
+enum KernelId {
+    K_sizeofRay, K_sizeofPoi, K_initAcu, K_initTrace, K_sphereTrace, K_triangleTrace, K_meshTrace, K_lightRender,
+    K_initShadowTrace, K_sphereShadowTrace, K_triangleShadowTrace, K_sceneRender, K_bouncePaths, K_copyToPixel,
+    K_a01_raytrace, K_a04_sizeofRay, K_a04_initTrace, K_a04_meshTrace, K_a07_sizeofRay, K_a07_initTrace, K_a07_meshTrace, K_a07_molTrace, K_COUNT
+};
+
+struct KernelSpec { const char* name; KernelId id; std::vector<ArgType> args; };
+
+struct KArg {
+    bool set = false;
+    mirt_buf* buf = nullptr;
+    union { uint32_t u; float f; float v[16]; } val;
+};
+
 struct mirt_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
@@ -74,12 +90,21 @@ struct mirt_ctx {
     std::unordered_set<mirt_kernel*> kernels;
     std::unordered_set<mirt_graph*> graphs;
     mirt_group* group = nullptr;  // set when the context belongs to a device group (mirt_group_create)
+    // command-stream fusion (mirt_ctx_set_fusion): enqueues of the Assign10 pass kernels held back until the pass is complete
+    int fusion = 0;
+    struct Pending { const KernelSpec* spec; std::vector<KArg> args; unsigned dim; size_t g[3]; };
+    std::vector<Pending> pending;
+    uint64_t fused_passes = 0;    // passes executed as ONE fused launch because their enqueue stream matched executeRender's
     // what a recording has touched so far (mirt_graph pins): device allocations a replay will read or write
     uint64_t scratch_gen = 1, defer_gen = 1;   // bumped whenever the allocation is replaced
     struct Pin { mirt_buf* buf; uint64_t uid; uint64_t prep_gen; uint64_t version; bool content; };
     std::vector<Pin> cap_pins;
     bool cap_scratch = false, cap_defer = false;
 };
+
+// held-back enqueues (command-stream fusion, below): every entry point that observes or changes device state runs them first
+static int flush_pending(mirt_ctx* ctx);
+#define FLUSH_PENDING(ctx) do { if (!(ctx)->pending.empty()) { int _rc = flush_pending(ctx); if (_rc) return _rc; } } while (0)
 
 struct mirt_graph {
     mirt_ctx* ctx = nullptr;
@@ -109,15 +134,6 @@ struct mirt_buf {
     uint64_t prep_gen = 1;    // bumped whenever `prep` is freed or replaced
     bool prep_sane = false;   // every plane-normal component is 0 or in [2^-40, 2^40]
 };
-
-enum ArgType { A_BUF, A_U32, A_F32, A_F16, A_AABB };
-enum KernelId {
-    K_sizeofRay, K_sizeofPoi, K_initAcu, K_initTrace, K_sphereTrace, K_triangleTrace, K_meshTrace, K_lightRender,
-    K_initShadowTrace, K_sphereShadowTrace, K_triangleShadowTrace, K_sceneRender, K_bouncePaths, K_copyToPixel,
-    K_a01_raytrace, K_a04_sizeofRay, K_a04_initTrace, K_a04_meshTrace, K_a07_sizeofRay, K_a07_initTrace, K_a07_meshTrace, K_a07_molTrace, K_COUNT
-};
-
-struct KernelSpec { const char* name; KernelId id; std::vector<ArgType> args; };
 
 static const std::vector<KernelSpec>& kernel_table() {
     // argument lists: A10 code.cl:440-1386 as bound by A10 code.js
@@ -150,12 +166,6 @@ static const std::vector<KernelSpec>& kernel_table() {
     };
     return t;
 }
-
-struct KArg {
-    bool set = false;
-    mirt_buf* buf = nullptr;
-    union { uint32_t u; float f; float v[16]; } val;
-};
 
 struct mirt_kernel {
     mirt_ctx* ctx = nullptr;
@@ -374,6 +384,7 @@ static int create_ctx(int device, mirt_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, MIRT_E_DEVICE, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
+    if (const char* f = getenv("MIRT_FUSION")) c->fusion = atoi(f) >= 2 ? 2 : 0;   // same as mirt_ctx_set_fusion: for hosts that cannot be edited at all
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
     for (auto& e : c->pe) (void)hipEventCreate(&e);
@@ -385,6 +396,7 @@ static int create_ctx(int device, mirt_ctx** out) {
 static int destroy_ctx(mirt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->capturing) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(ctx->stream, &g); if (g) (void)hipGraphDestroy(g); ctx->capturing = false; }
+    (void)flush_pending(ctx);   // held-back enqueues may write wrapped (caller-owned) memory: they still run
     (void)hipStreamSynchronize(ctx->stream);
     // whatever the host never released goes with the context; those handles become MIRT_E_HANDLE
     while (!ctx->graphs.empty()) free_graph(*ctx->graphs.begin(), true);
@@ -519,6 +531,7 @@ int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes,
     if (!live_group(g)) return fail(nullptr, MIRT_E_HANDLE, "mirt_gather: unknown group");
     const int n = (int)g->ctxs.size();
     mirt_ctx* rc_ctx = g->ctxs[0];
+    for (auto* c : g->ctxs) FLUSH_PENDING(c);
     if (!tiles || !tile_bytes || root < 0 || root >= n) return fail(rc_ctx, MIRT_E_ARG, "mirt_gather: null argument or root out of range");
     mirt_ctx* rootc = g->ctxs[root];
     uint64_t total = 0;
@@ -561,6 +574,7 @@ int mirt_group_finish(mirt_group* g) try {
     if (!live_group(g)) return fail(nullptr, MIRT_E_HANDLE, "mirt_group_finish: unknown group");
     for (auto* c : g->ctxs) {
         NOT_WHILE_CAPTURING(c, "mirt_group_finish");
+        FLUSH_PENDING(c);
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -575,6 +589,7 @@ const char* mirt_last_error(mirt_ctx* ctx) try {
 int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_stream: unknown context");
     NOT_WHILE_CAPTURING(ctx, "mirt_ctx_set_stream");
+    FLUSH_PENDING(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return MIRT_OK;
@@ -583,6 +598,7 @@ int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream) try {
 int mirt_finish(mirt_ctx* ctx) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_finish: unknown context");
     NOT_WHILE_CAPTURING(ctx, "mirt_finish");
+    if (ctx->fusion >= 2 && !ctx->pending.empty()) return MIRT_OK;   // inside a held pass (the reference calls finish() after every sceneRender, A10 code.js:1406): nothing is observable until a read, which flushes
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MIRT_OK;
@@ -618,6 +634,7 @@ int mirt_buf_wrap(mirt_ctx* ctx, void* device_ptr, size_t bytes, mirt_buf** out)
 
 int mirt_buf_release(mirt_buf* buf) try {
     if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_release: unknown or already released buffer");
+    if (live_has(buf->ctx)) { mirt_ctx* ctx = buf->ctx; FLUSH_PENDING(ctx); }
     free_buf(buf, live_has(buf->ctx));
     return MIRT_OK;
 } MIRT_CATCH("mirt_buf_release", return MIRT_E_DEVICE)
@@ -636,6 +653,7 @@ int mirt_buf_write(mirt_buf* buf, size_t offset, size_t nbytes, const void* host
     if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_write: unknown buffer");
     mirt_ctx* ctx = buf->ctx;
     NOT_WHILE_CAPTURING(ctx, "mirt_buf_write");
+    FLUSH_PENDING(ctx);
     if (!host && nbytes) return fail(ctx, MIRT_E_ARG, "mirt_buf_write: null host pointer");
     if (offset > buf->bytes || nbytes > buf->bytes - offset)
         return fail(ctx, MIRT_E_RANGE, "mirt_buf_write: [%zu, +%zu) exceeds buffer of %zu bytes", offset, nbytes, buf->bytes);
@@ -652,6 +670,7 @@ int mirt_buf_read(mirt_buf* buf, size_t offset, size_t nbytes, void* host, int b
     if (!live_has(buf)) return fail(nullptr, MIRT_E_HANDLE, "mirt_buf_read: unknown buffer");
     mirt_ctx* ctx = buf->ctx;
     NOT_WHILE_CAPTURING(ctx, "mirt_buf_read");
+    FLUSH_PENDING(ctx);
     if (!host && nbytes) return fail(ctx, MIRT_E_ARG, "mirt_buf_read: null host pointer");
     if (offset > buf->bytes || nbytes > buf->bytes - offset)
         return fail(ctx, MIRT_E_RANGE, "mirt_buf_read: [%zu, +%zu) exceeds buffer of %zu bytes", offset, nbytes, buf->bytes);
@@ -772,6 +791,168 @@ int mirt_kernel_set_arg_buf(mirt_kernel* k, unsigned index, mirt_buf* buf) try {
     return MIRT_OK;
 } MIRT_CATCH("mirt_kernel_set_arg_buf", return MIRT_E_DEVICE)
 
+// ---- command-stream fusion ---------------------------------------------------------------------------------------------------
+// The reference host issues one pass as 44+ enqueues (A10 code.js:1806-1854), every stage round-tripping Ray / Poi / shadow Ray / acu
+// through HBM: 4.2 KB per sample against the fused pass's 24 B.  With mirt_ctx_set_fusion(ctx, 2) the runtime holds the enqueues of
+// the Assign10 pass kernels back, and when the stream from an initTrace up to a copyToPixel IS executeRender's sequence over one
+// consistent set of buffers -- initTrace, the closest-hit kernels, lightRender per light, per light {initShadowTrace, any-hit kernels,
+// sceneRender}, any number of {bouncePaths, closest-hit kernels, per-light block}, copyToPixel -- it runs the pass as ONE launch of
+// k_fusedPass (render_pass_impl) + the recorded copyToPixel.  Anything else (a different order, mixed buffers, a read / write / release /
+// other command in between) flushes the held enqueues one by one, unchanged.  See include/mirt.h for what the mode trades.
+static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh);
+static int launch_kernel(mirt_ctx* ctx, const KernelSpec& S, std::vector<KArg>& a, unsigned dim, const size_t* global);
+
+static bool same_f(const float* x, const float* y, int n) { return memcmp(x, y, (size_t)n * 4) == 0; }
+
+// MIRT_OK: the held stream was a whole pass and has been executed fused.  1: not a pass (nothing executed).  < 0: error.
+static int try_fuse_pass(mirt_ctx* ctx, std::vector<mirt_ctx::Pending>& P) {
+    size_t i = 0;
+    auto id = [&](size_t k) { return k < P.size() ? P[k].spec->id : K_COUNT; };
+#define PB(k, j) (P[k].args[j].buf)
+#define PU(k, j) (P[k].args[j].val.u)
+#define PF(k, j) (P[k].args[j].val.f)
+#define PV(k, j) (P[k].args[j].val.v)
+    if (id(0) != K_initTrace || P[0].dim != 2) return 1;
+    mirt_buf *seeds = PB(0, 0), *rays = PB(0, 1), *pois = PB(0, 2);
+    const uint32_t rpp = PU(0, 7);
+    const uint32_t cols = f2u_host(PV(0, 4)[14]), rows = f2u_host(PV(0, 4)[15]);
+    if (!rpp || !cols || !rows || P[0].g[0] < cols || P[0].g[1] < rows) return 1;
+    const uint64_t total64 = (uint64_t)cols * rows * rpp;
+    if (total64 > 0xFFFFFFFFull) return 1;
+    const uint32_t total = (uint32_t)total64;
+    i = 1;
+    struct SetRef { int kind; mirt_buf *prims, *normals, *matid, *off; float bounds[8]; uint32_t n, mesh_matid; };
+    auto closest_group = [&](std::vector<SetRef>& out) -> bool {
+        for (;; ++i) {
+            const KernelId k = id(i);
+            if (k != K_sphereTrace && k != K_triangleTrace && k != K_meshTrace) return true;
+            if (PU(i, 0) != total || PB(i, 1) != pois || PB(i, 2) != rays || P[i].g[0] < total) return false;
+            SetRef r;
+            memset(&r, 0, sizeof r);
+            if (k == K_sphereTrace) { r.kind = 0; r.prims = PB(i, 3); r.matid = PB(i, 4); r.off = PB(i, 5); memcpy(r.bounds, PV(i, 6), 32); r.n = PU(i, 7); }
+            else if (k == K_triangleTrace) { r.kind = 1; r.prims = PB(i, 3); r.normals = PB(i, 4); r.matid = PB(i, 5); r.off = PB(i, 6); memcpy(r.bounds, PV(i, 7), 32); r.n = PU(i, 8); }
+            else { r.kind = 2; r.prims = PB(i, 3); r.normals = PB(i, 4); r.off = PB(i, 5); r.mesh_matid = PU(i, 6); memcpy(r.bounds, PV(i, 7), 32); r.n = PU(i, 8); }
+            out.push_back(r);
+        }
+    };
+    std::vector<SetRef> sets;
+    if (!closest_group(sets)) return 1;
+    // upload order the fused pass assumes: at most one sphere set, then at most one loose-triangle set, then the meshes
+    {
+        size_t k = 0;
+        if (k < sets.size() && sets[k].kind == 0) ++k;
+        if (k < sets.size() && sets[k].kind == 1) ++k;
+        for (; k < sets.size(); ++k) if (sets[k].kind != 2) return 1;
+        if (sets.size() > 2u + MIRT_MAX_MESHES) return 1;
+    }
+    struct LightRef { float light[16], shadow[16], scene[16]; };
+    std::vector<LightRef> lights;
+    mirt_buf *acu = nullptr, *shadow = nullptr, *material = nullptr;
+    for (; id(i) == K_lightRender; ++i) {
+        if (PB(i, 0) != pois || PB(i, 1) != rays || PU(i, 4) != total || P[i].g[0] < total) return 1;
+        if (acu && PB(i, 2) != acu) return 1;
+        acu = PB(i, 2);
+        LightRef L;
+        memset(&L, 0, sizeof L);
+        memcpy(L.light, PV(i, 3), 64);
+        lights.push_back(L);
+    }
+    if (lights.size() > MIRT_MAX_LIGHTS) return 1;
+    auto direct_block = [&](bool first) -> bool {
+        for (size_t l = 0; l < lights.size(); ++l) {
+            if (id(i) != K_initShadowTrace || PB(i, 1) != pois || PU(i, 2) != total || PB(i, 4) != seeds || P[i].g[0] < total) return false;
+            if (shadow && PB(i, 0) != shadow) return false;
+            shadow = PB(i, 0);
+            if (first) memcpy(lights[l].shadow, PV(i, 3), 64); else if (!same_f(lights[l].shadow, PV(i, 3), 16)) return false;
+            ++i;
+            for (const SetRef& r : sets) {   // one any-hit kernel per set, same order, same geometry
+                const KernelId want = r.kind == 0 ? K_sphereShadowTrace : K_triangleShadowTrace;
+                if (id(i) != want || PU(i, 0) != total || PB(i, 1) != shadow || PB(i, 2) != r.prims || PB(i, 3) != r.off ||
+                    !same_f(PV(i, 4), r.bounds, 8) || PU(i, 5) != r.n || P[i].g[0] < total) return false;
+                ++i;
+            }
+            if (id(i) != K_sceneRender || PB(i, 0) != acu || PB(i, 1) != pois || PB(i, 2) != shadow || PU(i, 5) != total || P[i].g[0] < total) return false;
+            if (material && PB(i, 3) != material) return false;
+            material = PB(i, 3);
+            if (first) memcpy(lights[l].scene, PV(i, 4), 64); else if (!same_f(lights[l].scene, PV(i, 4), 16)) return false;
+            ++i;
+        }
+        return true;
+    };
+    if (lights.empty() || !direct_block(true)) return 1;     // a scene without lights has no sceneRender to take acu / material from: not fused
+    uint32_t bounces = 0;
+    while (id(i) == K_bouncePaths) {
+        if (PB(i, 0) != pois || PB(i, 1) != rays || PB(i, 2) != seeds || PU(i, 3) != total || P[i].g[0] < total) return 1;
+        ++i;
+        std::vector<SetRef> again;
+        if (!closest_group(again) || again.size() != sets.size()) return 1;
+        for (size_t k = 0; k < sets.size(); ++k)
+            if (again[k].kind != sets[k].kind || again[k].prims != sets[k].prims || again[k].normals != sets[k].normals || again[k].matid != sets[k].matid ||
+                again[k].off != sets[k].off || again[k].n != sets[k].n || again[k].mesh_matid != sets[k].mesh_matid || !same_f(again[k].bounds, sets[k].bounds, 8)) return 1;
+        if (!direct_block(false)) return 1;
+        ++bounces;
+    }
+    if (id(i) != K_copyToPixel || i + 1 != P.size()) return 1;
+    if (PB(i, 1) != acu || PU(i, 3) != cols * rows || PU(i, 4) != rpp || P[i].g[0] < cols * rows) return 1;
+    {   // the fused pass takes k x k rays per pixel only (see render_pass_impl)
+        const uint32_t k = (uint32_t)std::sqrt((double)rpp);
+        const uint32_t kk = (k + 1) * (k + 1) == rpp ? k + 1 : k;
+        if (kk * kk != rpp) return 1;
+    }
+    // ---- it is a pass: one fused launch + the recorded copyToPixel
+    mirt_pass_desc d;
+    memset(&d, 0, sizeof d);
+    d.struct_size = sizeof d;
+    d.width = cols; d.height = rows; d.rays_per_pixel = rpp; d.bounces = bounces; d.pass_index = 1;
+    memcpy(d.cam, PV(0, 4), 64);
+    memcpy(d.scene_bounds, PV(0, 3), 32);
+    d.focal_length = PF(0, 5); d.lens_rad = PF(0, 6);
+    std::vector<mirt_grid> grids(sets.size());
+    std::vector<mirt_light> ls(lights.size());
+    for (size_t k = 0; k < sets.size(); ++k) {
+        grids[k].prims = sets[k].prims; grids[k].normals = sets[k].normals; grids[k].matid = sets[k].matid; grids[k].cell_offsets = sets[k].off;
+        memcpy(grids[k].bounds, sets[k].bounds, 32);
+        grids[k].n_slabs = sets[k].n; grids[k].mesh_matid = sets[k].mesh_matid;
+    }
+    size_t k = 0;
+    if (k < sets.size() && sets[k].kind == 0) d.spheres = &grids[k++];
+    if (k < sets.size() && sets[k].kind == 1) d.triangles = &grids[k++];
+    d.meshes = k < sets.size() ? &grids[k] : nullptr;
+    d.n_meshes = (uint32_t)(sets.size() - k);
+    for (size_t l = 0; l < lights.size(); ++l) { memcpy(ls[l].light, lights[l].light, 64); memcpy(ls[l].shadow, lights[l].shadow, 64); memcpy(ls[l].scene, lights[l].scene, 64); }
+    d.lights = ls.data(); d.n_lights = (uint32_t)ls.size();
+    d.material = material; d.seeds = seeds; d.acu = acu;
+    int rc = render_pass_impl(ctx, &d, false);
+    if (rc && rc != MIRT_E_DEVICE) return 1;   // refused before anything was launched (a size, a grid that fails validation ...): run the stream as issued,
+    if (rc) return rc;                          // whose own checks then report it against the kernel that trips it
+    rc = launch_kernel(ctx, *P[i].spec, P[i].args, P[i].dim, P[i].g);
+    if (rc) return rc;
+    ctx->fused_passes++;
+    return MIRT_OK;
+#undef PB
+#undef PU
+#undef PF
+#undef PV
+}
+
+// run whatever is held back: as one fused pass when it is one, else enqueue by enqueue, unchanged
+static int flush_pending(mirt_ctx* ctx) {
+    if (ctx->pending.empty()) return MIRT_OK;
+    std::vector<mirt_ctx::Pending> P;
+    P.swap(ctx->pending);
+    for (auto& p : P)
+        for (size_t j = 0; j < p.args.size(); ++j)
+            if (p.spec->args[j] == A_BUF && (!live_has(p.args[j].buf) || p.args[j].buf->ctx != ctx))
+                return fail(ctx, MIRT_E_HANDLE, "%s: a buffer of a held-back enqueue was released", p.spec->name);
+    int rc = try_fuse_pass(ctx, P);
+    if (rc <= 0) return rc;
+    for (auto& p : P)
+        if ((rc = launch_kernel(ctx, *p.spec, p.args, p.dim, p.g))) return rc;
+    return MIRT_OK;
+}
+
+static bool is_pass_kernel(KernelId k) { return k >= K_initTrace && k <= K_copyToPixel; }
+
 int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* global, const size_t* local) try {
     (void)local;  // no kernel uses local memory or barriers: the work-group shape is ours to choose
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_enqueue: unknown context");
@@ -785,9 +966,24 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
     }
     for (unsigned d = 0; d < dim; ++d)
         if (global[d] > 0xFFFFFFFFull) return fail(ctx, MIRT_E_ARG, "%s: global size exceeds 2^32", S.name);
+    if (ctx->fusion >= 2 && !ctx->capturing && is_pass_kernel(S.id)) {
+        if (S.id == K_initTrace) FLUSH_PENDING(ctx);                 // a new pass begins: whatever was held is not one
+        if (S.id == K_initTrace || !ctx->pending.empty()) {
+            mirt_ctx::Pending p;
+            p.spec = &S; p.args = k->args; p.dim = dim;
+            for (unsigned d = 0; d < 3; ++d) p.g[d] = d < dim ? global[d] : 1;
+            ctx->pending.push_back(std::move(p));
+            if (S.id == K_copyToPixel) return flush_pending(ctx);    // the pass is complete: run it now
+            return MIRT_OK;
+        }
+    }
+    FLUSH_PENDING(ctx);
+    return launch_kernel(ctx, S, k->args, dim, global);
+} MIRT_CATCH("mirt_enqueue", return MIRT_E_DEVICE)
+
+static int launch_kernel(mirt_ctx* ctx, const KernelSpec& S, std::vector<KArg>& a, unsigned dim, const size_t* global) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    auto& a = k->args;
     const uint32_t g0 = (uint32_t)global[0];
     int rc;
 #define BUF(i) (a[i].buf)
@@ -967,7 +1163,7 @@ int mirt_enqueue(mirt_ctx* ctx, mirt_kernel* k, unsigned dim, const size_t* glob
 #undef V
     HIPCHK(ctx, hipGetLastError());
     return MIRT_OK;
-} MIRT_CATCH("mirt_enqueue", return MIRT_E_DEVICE)
+}
 
 static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool tri, bool per_prim_matid, pt::GridArgs* o) {
     if (!g->prims || !g->cell_offsets) return fail(ctx, MIRT_E_ARG, "%s: null geometry buffer", what);
@@ -1102,17 +1298,34 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     return MIRT_OK;
 }
 
-int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) try { return render_pass_impl(ctx, d, false); } MIRT_CATCH("mirt_render_pass", return MIRT_E_DEVICE)
-int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* d) try { return render_pass_impl(ctx, d, true); } MIRT_CATCH("mirt_render_first_pass", return MIRT_E_DEVICE)
+int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* d) try { if (live_has(ctx)) FLUSH_PENDING(ctx); return render_pass_impl(ctx, d, false); } MIRT_CATCH("mirt_render_pass", return MIRT_E_DEVICE)
+int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* d) try { if (live_has(ctx)) FLUSH_PENDING(ctx); return render_pass_impl(ctx, d, true); } MIRT_CATCH("mirt_render_first_pass", return MIRT_E_DEVICE)
+
+int mirt_ctx_set_fusion(mirt_ctx* ctx, int level) try {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_fusion: unknown context");
+    if (level != 0 && level != 2) return fail(ctx, MIRT_E_ARG, "mirt_ctx_set_fusion: level is 0 (every enqueue launches) or 2 (whole passes are fused)");
+    FLUSH_PENDING(ctx);
+    ctx->fusion = level;
+    return MIRT_OK;
+} MIRT_CATCH("mirt_ctx_set_fusion", return MIRT_E_DEVICE)
+
+int mirt_ctx_fused_passes(mirt_ctx* ctx, uint64_t* count) try {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_fused_passes: unknown context");
+    if (!count) return fail(ctx, MIRT_E_ARG, "mirt_ctx_fused_passes: null output");
+    *count = ctx->fused_passes;
+    return MIRT_OK;
+} MIRT_CATCH("mirt_ctx_fused_passes", return MIRT_E_DEVICE)
 
 int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_exact_only: unknown context");
+    FLUSH_PENDING(ctx);
     ctx->force_exact = on != 0;
     return MIRT_OK;
 } MIRT_CATCH("mirt_ctx_set_exact_only", return MIRT_E_DEVICE)
 
 int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_pass_deferred: unknown context");
+    FLUSH_PENDING(ctx);
     NOT_WHILE_CAPTURING(ctx, "mirt_pass_deferred");
     if (!samples) return fail(ctx, MIRT_E_ARG, "mirt_pass_deferred: null output");
     *samples = 0;
@@ -1131,6 +1344,7 @@ int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) try {
 
 int mirt_ctx_set_profiling(mirt_ctx* ctx, int on) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_ctx_set_profiling: unknown context");
+    FLUSH_PENDING(ctx);
     ctx->profiling = on != 0;
     ctx->pe_valid = false;
     return MIRT_OK;
@@ -1138,6 +1352,7 @@ int mirt_ctx_set_profiling(mirt_ctx* ctx, int on) try {
 
 int mirt_pass_timing(mirt_ctx* ctx, float* fused_ms, float* resolve_ms) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_pass_timing: unknown context");
+    FLUSH_PENDING(ctx);
     if (!ctx->pe_valid) return fail(ctx, MIRT_E_ARG, "mirt_pass_timing: no profiled mirt_render_pass yet (mirt_ctx_set_profiling)");
     HIPCHK(ctx, hipEventSynchronize(ctx->pe[2]));
     float a = 0.f, b = 0.f;
@@ -1150,6 +1365,7 @@ int mirt_pass_timing(mirt_ctx* ctx, float* fused_ms, float* resolve_ms) try {
 
 int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, uint64_t count, uint32_t seed_base) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_seed_fill: unknown context");
+    FLUSH_PENDING(ctx);
     int rc = need(ctx, "mirt_seed_fill", seeds, count * 4);
     if (rc) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1161,6 +1377,7 @@ int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, uint64_t 
 
 int mirt_zero(mirt_ctx* ctx, mirt_buf* buf) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_zero: unknown context");
+    FLUSH_PENDING(ctx);
     int rc = need(ctx, "mirt_zero", buf, 0);
     if (rc) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1171,6 +1388,7 @@ int mirt_zero(mirt_ctx* ctx, mirt_buf* buf) try {
 
 int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_numerics: unknown context");
+    FLUSH_PENDING(ctx);
     int rc;
     if (!((op >= 0 && op <= 14) || (op >= 20 && op <= 27))) return fail(ctx, MIRT_E_ARG, "mirt_debug_numerics: op %d outside 0..14, 20..27", op);
     const bool vec = op >= 20 && op != 25;
@@ -1192,6 +1410,7 @@ static int new_owned(mirt_ctx* ctx, size_t bytes, mirt_buf** out) {
 
 int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cell_offsets, mirt_buf** order, uint32_t* total) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_build: unknown context");
+    FLUSH_PENDING(ctx);
     if (!d || d->struct_size != sizeof(mirt_grid_build_desc) || !cell_offsets || !order || !total)
         return fail(ctx, MIRT_E_ARG, "mirt_grid_build: null argument or descriptor size mismatch");
     *cell_offsets = *order = nullptr;
@@ -1229,6 +1448,7 @@ int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cel
 int mirt_grid_gather_triangles(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* pos_f64, mirt_buf* nor_f64, uint32_t nsteps,
                                const int32_t* ops, const double* vecs, float pad_w, mirt_buf** pos_out, mirt_buf** nor_out) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_triangles: unknown context");
+    FLUSH_PENDING(ctx);
     if (!pos_out || nsteps > 4 || (nsteps && (!ops || !vecs))) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_triangles: bad argument");
     for (uint32_t i = 0; i < nsteps; ++i) if (ops[i] < 0 || ops[i] > 2) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_triangles: op %d", ops[i]);
     int rc;
@@ -1260,6 +1480,7 @@ int mirt_grid_gather_triangles(mirt_ctx* ctx, mirt_buf* order, uint32_t total, m
 
 int mirt_mesh_ingest(mirt_ctx* ctx, const mirt_mesh_ingest_desc* d, mirt_buf* pos9_out, mirt_buf* nor9_out, mirt_buf* bounds6) {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_mesh_ingest: unknown context");
+    FLUSH_PENDING(ctx);
     if (!d || d->struct_size != sizeof(mirt_mesh_ingest_desc)) return fail(ctx, MIRT_E_ARG, "mirt_mesh_ingest: null descriptor or size mismatch");
     NOT_WHILE_CAPTURING(ctx, "mirt_mesh_ingest");
     if (d->n_corners % 3u) return fail(ctx, MIRT_E_ARG, "mirt_mesh_ingest: %u corners is not a whole number of triangles", d->n_corners);
@@ -1299,6 +1520,7 @@ static int check_order(mirt_ctx* ctx, mirt_buf* order, uint32_t total, uint64_t 
 
 int mirt_grid_gather_spheres(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* sph_f64, mirt_buf** out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_spheres: unknown context");
+    FLUSH_PENDING(ctx);
     if (!out) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_spheres: null out");
     int rc;
     if ((rc = need(ctx, "gather order", order, (uint64_t)total * 4))) return rc;
@@ -1314,6 +1536,7 @@ int mirt_grid_gather_spheres(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mir
 
 int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* in_u32, mirt_buf** out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_u32: unknown context");
+    FLUSH_PENDING(ctx);
     if (!out) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_u32: null out");
     int rc;
     if ((rc = need(ctx, "gather order", order, (uint64_t)total * 4))) return rc;
@@ -1329,6 +1552,7 @@ int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_bu
 
 int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, mirt_buf* out16) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_divcheck: unknown context");
+    FLUSH_PENDING(ctx);
     int rc = need(ctx, "mirt_debug_divcheck out", out16, 16 * 8);
     if (rc) return rc;
     if (mode < 0 || mode > 5) return fail(ctx, MIRT_E_ARG, "mirt_debug_divcheck: mode is 0..5");
@@ -1343,6 +1567,7 @@ int mirt_debug_divcheck(mirt_ctx* ctx, int mode, uint64_t seed, uint64_t count, 
 
 int mirt_capture_begin(mirt_ctx* ctx) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_capture_begin: unknown context");
+    FLUSH_PENDING(ctx);
     if (ctx->capturing) return fail(ctx, MIRT_E_ARG, "mirt_capture_begin: already recording");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
@@ -1382,6 +1607,7 @@ int mirt_capture_end(mirt_ctx* ctx, mirt_graph** out) try {
 
 int mirt_graph_launch(mirt_ctx* ctx, mirt_graph* graph) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_graph_launch: unknown context");
+    FLUSH_PENDING(ctx);
     if (!live_has(graph) || graph->ctx != ctx) return fail(ctx, MIRT_E_HANDLE, "mirt_graph_launch: unknown graph");
     NOT_WHILE_CAPTURING(ctx, "mirt_graph_launch");
     // the recording holds raw device pointers: refuse to replay once any of them has been freed, replaced or (for validated /
@@ -1407,6 +1633,7 @@ int mirt_graph_release(mirt_graph* graph) try {
 
 int mirt_timer_start(mirt_ctx* ctx) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_timer_start: unknown context");
+    FLUSH_PENDING(ctx);
     NOT_WHILE_CAPTURING(ctx, "mirt_timer_start");
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return MIRT_OK;
@@ -1414,6 +1641,7 @@ int mirt_timer_start(mirt_ctx* ctx) try {
 
 int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_timer_stop_ms: unknown context");
+    FLUSH_PENDING(ctx);
     NOT_WHILE_CAPTURING(ctx, "mirt_timer_stop_ms");
     if (!ms) return fail(ctx, MIRT_E_ARG, "mirt_timer_stop_ms: null output");
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));

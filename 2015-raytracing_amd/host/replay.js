@@ -23,6 +23,7 @@ function replay(trace, blob, hooks) {
   hooks = hooks || {};
   const webcl = hooks.webcl || real.webcl;   // tests replay onto a second recorder to prove the replayer re-issues the stream unchanged
   const obj = new Map(), roles = new Map(), reads = [], dumps = {}, checked = { preferredMultiple: 0, structSizes: 0 };
+  let fusedPasses = 0;
   const get = (id) => { const o = obj.get(id); if (!o) throw new Error("trace refers to unknown object " + id); return o; };
   const typed = (e, bytes) => { const T = TYPES[e.type]; const c = Buffer.from(bytes); return new T(c.buffer, c.byteOffset, c.length / T.BYTES_PER_ELEMENT); };
   const payload = (e) => typed(e, e.hex !== undefined ? Buffer.from(e.hex, "hex") : blob.slice(e.blob.off, e.blob.off + e.blob.len));
@@ -75,6 +76,7 @@ function replay(trace, blob, hooks) {
           queue.enqueueReadBuffer(o, true, 0, o.byteLength, out, []); queue.finish();
           dumps[roles.get(e.id)] = out;
         }
+        if (e.kind === "context" && typeof o.fusedPasses === "function") fusedPasses += o.fusedPasses();   // ours: how many passes ran fused (MIRT_FUSION=2)
         o.release(); obj.delete(e.id);
         break;
       }
@@ -82,7 +84,7 @@ function replay(trace, blob, hooks) {
     }
     if (hooks.after) hooks.after(e);
   }
-  return { reads: reads.map((r) => Buffer.from(r.dst.buffer, 0, r.event.bytes)), dumps: dumps, checked: checked, device: devices[0].getInfo(webcl.DEVICE_NAME), leaked: obj.size };
+  return { reads: reads.map((r) => Buffer.from(r.dst.buffer, 0, r.event.bytes)), dumps: dumps, checked: checked, device: devices[0].getInfo(webcl.DEVICE_NAME), leaked: obj.size, fusedPasses: fusedPasses };
 }
 
 function load(prefix) {
@@ -96,9 +98,11 @@ if (require.main === module) {
   const a = process.argv.slice(2);
   if (a.length < 2) { process.stderr.write("usage: node replay.js <trace-prefix> <out-prefix>\n"); process.exit(2); }
   const { trace, blob } = load(a[0]);
+  const t0 = process.hrtime.bigint();
   const r = replay(trace, blob);
+  const ms = Number(process.hrtime.bigint() - t0) / 1e6;
   fs.writeFileSync(a[1] + ".reads.bin", Buffer.concat(r.reads));
   for (const k of Object.keys(r.dumps)) fs.writeFileSync(a[1] + "." + k + ".bin", Buffer.from(r.dumps[k].buffer));
-  process.stdout.write(JSON.stringify({ events: trace.events.length, reads: r.reads.map((b) => b.length), checked: r.checked, device: r.device, leaked: r.leaked }) + "\n");
+  process.stdout.write(JSON.stringify({ events: trace.events.length, reads: r.reads.map((b) => b.length), checked: r.checked, device: r.device, leaked: r.leaked, fusedPasses: r.fusedPasses, ms: ms }) + "\n");
 }
 module.exports = { replay, load };

@@ -259,6 +259,10 @@ class WebCLContext {
   createCommandQueue() { return new WebCLCommandQueue(this); }
   createProgram(source) { return new WebCLProgram(this, source); }
   createBuffer(flags, bytes) { return new WebCLBuffer(this, bytes, flags); }
+  // extension (mirt_ctx_set_fusion): level 2 runs a whole executeRender pass issued kernel by kernel as one fused launch.
+  // A page that cannot be edited gets the same from the environment variable MIRT_FUSION=2.
+  setFusion(level) { wrap(() => native().ctxSetFusion(this.h, level)); }
+  fusedPasses() { return wrap(() => native().ctxFusedPasses(this.h)); }
   release() { if (this.h && !this.grouped) wrap(() => native().ctxDestroy(this.h)); this.h = null; }
 }
 

@@ -86,6 +86,8 @@ SYMBOLS = {
     "mirt_render_first_pass": (C.c_int, [C.c_void_p, C.POINTER(_PassDesc)]),
     "mirt_pass_deferred": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mirt_ctx_set_exact_only": (C.c_int, [C.c_void_p, C.c_int]),
+    "mirt_ctx_set_fusion": (C.c_int, [C.c_void_p, C.c_int]),
+    "mirt_ctx_fused_passes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mirt_seed_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]),
     "mirt_zero": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mirt_timer_start": (C.c_int, [C.c_void_p]),
@@ -275,6 +277,15 @@ class Context:
 
     def set_exact_only(self, on=True):
         self._chk(lib().mirt_ctx_set_exact_only(self.h, 1 if on else 0))
+
+    def set_fusion(self, level=2):
+        """command-stream fusion (include/mirt.h): 2 = whole executeRender passes issued kernel by kernel run as one fused launch"""
+        self._chk(lib().mirt_ctx_set_fusion(self.h, int(level)))
+
+    def fused_passes(self):
+        n = C.c_uint64()
+        self._chk(lib().mirt_ctx_fused_passes(self.h, C.byref(n)))
+        return n.value
 
     def set_profiling(self, on=True):
         self._chk(lib().mirt_ctx_set_profiling(self.h, 1 if on else 0))

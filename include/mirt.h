@@ -187,6 +187,28 @@ MIRT_API int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
 MIRT_API int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples);
 MIRT_API int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on);
 
+/* Command-stream fusion: the reference host's pass, kernel by kernel, at the fused pass's speed -- with no change to the host.
+ * executeRender (A10 code.js:1806-1854) issues a pass as 44+ enqueues whose every stage round-trips Ray / Poi / shadow Ray / acu
+ * through HBM (4.2 KB per sample; the fused pass moves 24 B).  At level 2 the runtime holds back the enqueues of the Assign10 pass
+ * kernels from an initTrace on, and when the stream up to the copyToPixel IS executeRender's sequence over one consistent set of
+ * buffers and arguments -- initTrace; sphere / triangle / mesh Trace; lightRender per light; per light {initShadowTrace, the
+ * any-hit kernel of every set, sceneRender}; any number of {bouncePaths, closest-hit kernels, that per-light block}; copyToPixel --
+ * it runs as ONE launch of the fused pass + the recorded copyToPixel.  Anything else is launched enqueue by enqueue, in order,
+ * exactly as at level 0: a different kernel order, mixed buffers or changed geometry arguments inside the pass, a global size
+ * smaller than the ray count, and any command that observes or changes device state while enqueues are held (buffer read / write /
+ * release, mirt_zero, mirt_seed_fill, mirt_render_pass, capture, timers, gather, destroy ...) flush the held stream first.
+ * What level 2 trades, and why it is off by default:
+ *   - seeds, acu and pixel after the pass are bit-identical to level 0 (tests/test_fusion.py replays the reference host's own call
+ *     stream both ways); the Ray, Poi and shadow-Ray buffers are NOT written by a fused pass -- they keep their previous contents.
+ *     The reference host never reads them (it cannot: it does not know their layout beyond sizeof).
+ *   - mirt_finish inside a held pass returns without draining anything (the reference calls finish() after every sceneRender,
+ *     code.js:1406); the work runs at the copyToPixel.  Host-side timing of individual kernels is therefore meaningless.
+ *   - errors of a held enqueue (a buffer too small, a grid failing validation) are reported by the call that flushes it.
+ * Level 0 (default): every enqueue launches its kernel.  The environment variable MIRT_FUSION=2 sets the level of every new
+ * context.  mirt_ctx_fused_passes: how many passes of this context ran fused. */
+MIRT_API int mirt_ctx_set_fusion(mirt_ctx* ctx, int level);
+MIRT_API int mirt_ctx_fused_passes(mirt_ctx* ctx, uint64_t* count);
+
 /* seeds[i] = 1 + (mix32((first_ray + i) ^ 0x9E3779B9 ^ seed_base) mod 2147483646): the
  * reproducible stand-in for the host's Math.random() seeding (A10 code.js:1140-1146). */
 MIRT_API int mirt_seed_fill(mirt_ctx* ctx, mirt_buf* seeds, uint64_t first_ray, uint64_t count, uint32_t seed_base);

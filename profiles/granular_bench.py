@@ -22,6 +22,19 @@ for rpp in [int(x) for x in os.environ.get("RPPS", "16,64").split(",")]:
         gr.execute_render()
     ctx.finish()
     dt = (time.perf_counter() - t0) / n
+    # the same enqueues with command-stream fusion on (mirt_ctx_set_fusion(ctx, 2)): the runtime recognises executeRender's stream
+    ctx.set_fusion(2)
+    f0 = ctx.fused_passes()
+    gf = render.GranularRenderer(ctx, sc)
+    gf.execute_render()
+    t2 = time.perf_counter()
+    for _ in range(n):
+        gf.execute_render()
+    ctx.finish()
+    dg = (time.perf_counter() - t2) / n
+    assert ctx.fused_passes() - f0 == n + 1
+    ctx.set_fusion(0)
+    gf.release()
     fr = render.FusedRenderer(ctx, sc, want_radiance=False)
     fr.execute_render()
     ctx.finish()
@@ -31,6 +44,7 @@ for rpp in [int(x) for x in os.environ.get("RPPS", "16,64").split(",")]:
     ctx.finish()
     df = (time.perf_counter() - t1) / n
     print(json.dumps({"rpp": rpp, "samples": sc.total_rays, "granular_ms_per_pass": round(dt * 1e3, 2), "granular_Msamples_s": round(sc.total_rays / dt / 1e6, 1),
-                      "granular_algorithmic_GBs": round(BYTES * sc.total_rays / dt / 1e9, 1), "fused_ms_per_pass": round(df * 1e3, 2),
+                      "granular_algorithmic_GBs": round(BYTES * sc.total_rays / dt / 1e9, 1), "granular_stream_fused_ms_per_pass": round(dg * 1e3, 2), "granular_stream_fused_Msamples_s": round(sc.total_rays / dg / 1e6, 1),
+                      "fused_ms_per_pass": round(df * 1e3, 2),
                       "fused_over_granular": round(dt / df, 2)}))
     gr.release(); fr.release()

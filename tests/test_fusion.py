@@ -1,0 +1,232 @@
+"""Command-stream fusion (mirt_ctx_set_fusion, include/mirt.h): the reference host's kernel-by-kernel pass at the fused pass's speed.
+
+The reference's executeRender (A10 code.js:1806-1854) issues a pass as 44+ enqueues.  At fusion level 2 the runtime recognises that
+stream and runs it as one launch of the fused pass.  What must hold:
+  - everything the host can observe (frames read back, the accumulator, the seed buffer) is bit-identical to level 0 and to the
+    compiled reference -- checked with the reference host's OWN recorded call stream (tests/golden/calltrace_*) and the fixtures;
+  - a stream that is not executeRender's (another order, mixed buffers, a read in the middle, a short NDRange) runs enqueue by
+    enqueue, unchanged;
+  - the Ray / Poi / shadow-Ray buffers are not written by a fused pass (documented trade).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import a10_pass as A
+import calltrace as CT
+from conftest import FULL_CASES, HOST, bits, load_fixture
+from test_calltrace import CASES, check_against_expectation, node, run_node
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx(pkg):
+    from raytracing_amd.pyhost import mirt
+    c = mirt.Context(0)
+    yield c
+    c.destroy()
+
+
+@pytest.mark.skipif(node is None, reason="node is not installed")
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_host_stream_fused_matches_compiled_reference(name, tmp_path):
+    """tests/test_calltrace.py's GPU test with MIRT_FUSION=2 in the environment -- the switch for a page that cannot be edited: the
+    reference host's unmodified stream, every pass of it fused, reads back the compiled reference's bytes."""
+    out = str(tmp_path / "r")
+    rep = json.loads(run_node(os.path.join(HOST, "replay.js"), CT.golden_prefix(name), out, env=dict(os.environ, MIRT_FUSION="2")))
+    assert rep["fusedPasses"] == CASES[name][4], rep
+    ex = np.load(CT.golden_prefix(name) + "_expect.npz")
+    raw = open(out + ".reads.bin", "rb").read()
+    reads, off = [], 0
+    for n in ex["read_sizes"].tolist():
+        reads.append(raw[off:off + n])
+        off += n
+    assert off == len(raw)
+    check_against_expectation(name, reads, open(out + ".acu.bin", "rb").read(), open(out + ".seeds.bin", "rb").read())
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_fused_stream_matches_fixtures(ctx, pkg, name):
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture(name)
+    ctx.set_fusion(2)
+    gr = render.GranularRenderer(ctx, sc, seeds=fx["seeds_in"])
+    rays0 = gr.read("rays").copy()
+    gr.execute_render()
+    assert ctx.fused_passes() == 1
+    assert np.array_equal(bits(gr.read("acu").reshape(-1, 4)), bits(fx["f_acu"])), "acu"
+    assert np.array_equal(gr.read("seeds"), fx["f_seeds"]), "seeds"
+    assert np.array_equal(gr.read("pixel").reshape(-1, 4), fx["pixel"]), "pixel"
+    assert np.array_equal(gr.read("rays"), rays0), "a fused pass leaves the Ray buffer alone"
+    gr.release()
+
+
+def test_progressive_passes_fused_and_unfused_agree(ctx, pkg):
+    """Five passes each way on one context: the pass counter in copyToPixel's scale (code.js:1412) travels with the recorded launch."""
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture("cornell_teapot3_32x24_r4")
+    a = render.GranularRenderer(ctx, sc, seeds=fx["seeds_in"])
+    frames = []
+    for _ in range(5):
+        a.execute_render()
+        frames.append((a.read("pixel").copy(), a.read("acu").copy(), a.read("seeds").copy()))
+    a.release()
+    assert ctx.fused_passes() == 0
+    ctx.set_fusion(2)
+    b = render.GranularRenderer(ctx, sc, seeds=fx["seeds_in"])
+    for p in range(5):
+        b.execute_render()
+        assert np.array_equal(b.read("pixel"), frames[p][0]), f"pixel, pass {p}"
+        assert np.array_equal(bits(b.read("acu")), bits(frames[p][1])) and np.array_equal(b.read("seeds"), frames[p][2]), f"pass {p}"
+    assert ctx.fused_passes() == 5
+    b.release()
+
+
+def _unfused(ctx, sc, seeds, drive):
+    from raytracing_amd.pyhost import render
+    ctx.set_fusion(0)
+    g = render.GranularRenderer(ctx, sc, seeds=seeds)
+    drive(g)
+    out = {k: g.read(k).copy() for k in ("acu", "seeds", "pixel", "rays", "pois", "shadow")}
+    g.release()
+    return out
+
+
+def _same(got, want, keys):
+    for k in keys:
+        a, b = got[k], want[k]
+        if k == "acu":
+            a, b = bits(a), bits(b)
+        assert np.array_equal(a, b), k
+
+
+STREAMS = {}
+
+
+def stream(f):
+    STREAMS[f.__name__] = f
+    return f
+
+
+@stream
+def read_in_the_middle(g):
+    """the host looks at the accumulator after the primary segment: the held enqueues run, the rest of the pass follows one by one"""
+    g.execute_render(on_primary=lambda gr: gr.read("acu"))
+
+
+@stream
+def bounce_before_the_light_block(g):
+    """not executeRender's order: bouncePaths straight after the closest-hit kernels"""
+    s, k = g.s, g.k
+    k["initTrace"].set_arg(4, s.cam).enqueue(g.gws["initTrace"], g.lws["initTrace"])
+    g._closest()
+    k["bouncePaths"].enqueue(g.g1, [64])
+    g._closest()
+    for l in s.lights:
+        k["lightRender"].set_arg(3, l["light"]).enqueue(g.g1, [64])
+    g._direct()
+    k["copyToPixel"].set_arg(2, np.float32([1.0 / s.rpp])).enqueue(g.gws["copyToPixel"], [64])
+    g.ctx.finish()
+
+
+@stream
+def short_ndrange(g):
+    """a global size below the ray count: the tail of the frame is not traced (min(global, count), as OpenCL would)"""
+    g.g1 = [64]
+    g.execute_render()
+
+
+@stream
+def no_copy_to_pixel(g):
+    """a pass that never reaches copyToPixel: whatever is held runs when the host reads"""
+    g._enqueue_segments(2)
+
+
+@stream
+def light_block_differs_in_a_bounce(g):
+    """the shadow constants of a light change between the primary and the bounce segments"""
+    s, k = g.s, g.k
+    k["initTrace"].set_arg(4, s.cam).enqueue(g.gws["initTrace"], g.lws["initTrace"])
+    g._closest()
+    for l in s.lights:
+        k["lightRender"].set_arg(3, l["light"]).enqueue(g.g1, [64])
+    g._direct()
+    keep = [l["shadow"] for l in s.lights]
+    for l in s.lights:
+        l["shadow"] = (np.asarray(l["shadow"], np.float32) * np.float32(0.5)).astype(np.float32)
+    try:
+        k["bouncePaths"].enqueue(g.g1, [64])
+        g._closest()
+        g._direct()
+    finally:
+        for l, v in zip(s.lights, keep):
+            l["shadow"] = v
+    k["copyToPixel"].set_arg(2, np.float32([1.0 / s.rpp])).enqueue(g.gws["copyToPixel"], [64])
+    g.ctx.finish()
+
+
+@pytest.mark.parametrize("which", sorted(STREAMS))
+def test_streams_that_are_not_a_pass_run_unchanged(ctx, pkg, which):
+    """Level 2 on a stream the matcher must refuse == level 0 on the same stream, for EVERY buffer (Ray / Poi / shadow included: nothing
+    was fused, so they are written as always)."""
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture("cornell_teapot3_32x24_r4")
+    want = _unfused(ctx, sc, fx["seeds_in"], STREAMS[which])
+    ctx.set_fusion(2)
+    g = render.GranularRenderer(ctx, sc, seeds=fx["seeds_in"])
+    STREAMS[which](g)
+    got = {k: g.read(k).copy() for k in want}
+    assert ctx.fused_passes() == 0
+    _same(got, want, want.keys())
+    g.release()
+
+
+def test_a_refused_stream_is_followed_by_fused_passes(ctx, pkg):
+    """the matcher carries no state from one pass to the next"""
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture("cornell_32x24_r4")
+
+    def drive(g):
+        read_in_the_middle(g)
+        g.execute_render()
+        g.execute_render()
+    want = _unfused(ctx, sc, fx["seeds_in"], drive)
+    ctx.set_fusion(2)
+    g = render.GranularRenderer(ctx, sc, seeds=fx["seeds_in"])
+    drive(g)
+    assert ctx.fused_passes() == 2
+    _same({k: g.read(k) for k in ("acu", "seeds", "pixel")}, want, ("acu", "seeds", "pixel"))
+    g.release()
+
+
+def test_errors_of_held_enqueues_surface_at_the_flush(ctx, pkg):
+    """a Ray buffer too small for the launch: level 0 reports it at the enqueue; level 2 when the held stream runs -- same code, same
+    kernel named -- and the context stays usable"""
+    from raytracing_amd.pyhost import mirt, render
+    fx, sc = load_fixture("cornell_32x24_r4")
+    ctx.set_fusion(2)
+    g = render.GranularRenderer(ctx, sc, seeds=fx["seeds_in"])
+    small = ctx.buffer(64)
+    g.k["bouncePaths"].set_arg(1, small)
+    with pytest.raises(mirt.MirtError) as e:
+        g.execute_render()
+        g.read("acu")
+    assert e.value.code == -5 and "bouncePaths" in str(e.value)
+    g.k["bouncePaths"].set_arg(1, g.b["rays"])
+    ctx.zero(g.b["acu"])
+    g.b["seeds"].write(np.asarray(fx["seeds_in"], np.int32))
+    g.passes = 1
+    g.execute_render()
+    assert np.array_equal(bits(g.read("acu").reshape(-1, 4)), bits(fx["f_acu"]))
+    small.release()
+    g.release()
+
+
+def test_level_is_validated(ctx, pkg):
+    from raytracing_amd.pyhost import mirt
+    with pytest.raises(mirt.MirtError) as e:
+        ctx.set_fusion(1)
+    assert e.value.code == -1
