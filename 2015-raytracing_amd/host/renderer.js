@@ -92,6 +92,7 @@ class GranularRenderer {
     this.device = opt.ctx ? opt.ctx.device : pickDevice(opt.device);
     this.useGraph = !!opt.graph;
     this.ctx = opt.ctx || webcl.createContext(this.device);           // createCLBasicResources (code.js:576-608)
+    if (opt.fusion && this.ctx.setFusion) this.ctx.setFusion(2);       // ours: the runtime runs each pass of this stream as one fused launch
     this.q = this.ctx.createCommandQueue();
     this.program = this.ctx.createProgram(MANIFEST);
     this.program.build();

@@ -203,7 +203,8 @@ MIRT_API int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on);
  *     The reference host never reads them (it cannot: it does not know their layout beyond sizeof).
  *   - mirt_finish inside a held pass returns without draining anything (the reference calls finish() after every sceneRender,
  *     code.js:1406); the work runs at the copyToPixel.  Host-side timing of individual kernels is therefore meaningless.
- *   - errors of a held enqueue (a buffer too small, a grid failing validation) are reported by the call that flushes it.
+ *   - errors of a held enqueue (a buffer too small, a grid failing validation) are reported by the call that flushes it, and the
+ *     held enqueues after the failing one are dropped (at level 0 the host would have stopped at that enqueue's exception).
  * Level 0 (default): every enqueue launches its kernel.  The environment variable MIRT_FUSION=2 sets the level of every new
  * context.  mirt_ctx_fused_passes: how many passes of this context ran fused. */
 MIRT_API int mirt_ctx_set_fusion(mirt_ctx* ctx, int level);

@@ -128,7 +128,7 @@ def test_webcl_surface_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fused", "granular", "fused+device-grid", "granular+device-grid"])
+@pytest.mark.parametrize("mode", ["fused", "granular", "granular+fusion", "fused+device-grid", "granular+device-grid"])
 @pytest.mark.parametrize("name", sorted(OWN_SCENES))
 def test_node_render_matches_compiled_reference(tmp_path, name, mode):
     """scene.xml -> JS host -> N-API addon -> C ABI -> HIP kernels -> frame, against the compiled reference's frame.
@@ -142,6 +142,8 @@ def test_node_render_matches_compiled_reference(tmp_path, name, mode):
         args.append("--granular")
     if "device-grid" in mode:
         args.append("--device-grid")
+    if "fusion" in mode:   # the same enqueues, recognised by the runtime and run as one fused launch per pass (mirt_ctx_set_fusion)
+        args.append("--fusion")
     run_node(*args)
     pix = np.fromfile(out, np.uint8).reshape(-1, 4)
     rad = np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)
