@@ -85,8 +85,8 @@ PT_DEV Box set_box(const GridArgs& S) {
 
 // closest hit over every set in upload order, z-buffered through ray.maxt
 // (A10 code.cl:675-800, 802-935, 937-1070; order A10 code.js:1809-1813)
-template <bool FAST, bool GRIDS>
-PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park, const uint32_t* tables, bool& defer) {
+template <bool FAST, int GRIDS>
+PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park, bool& defer) {
     if (FAST && !(ray.mint == ray.maxt)) defer = defer || !ray_guard(ray);   // a dead ray divides nothing
     for (uint32_t s = 0; s < A.n_sets; ++s) {
         const GridArgs& S = A.sets[s];
@@ -100,7 +100,7 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
             }
         } else if (live) {
             const BoxHit bh = inter_aabb_t<FAST, true>(ray, set_box(S));
-            if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, false, TRI_A10, FAST>(ray, bh, S, defer, tables) : trace_dda<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S, defer, tables);
+            if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, false, TRI_A10, FAST, GRIDS == 1>(ray, bh, S, defer) : trace_dda<TRIANGLES, false, TRI_A10, FAST, GRIDS == 1>(ray, bh, S, defer);
         }
         if (ch.idx == UINT32_MAX) continue;
         ray.maxt = ch.t;
@@ -122,8 +122,8 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
 
 // per light: shadow ray, any-hit over every set, shade (A10 code.js:1817-1826; code.cl:631-673,
 // 1073-1321, 1323-1364)
-template <bool FAST, bool GRIDS>
-PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc, const Park& park, const uint32_t* tables, bool& defer) {
+template <bool FAST, int GRIDS>
+PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc, const Park& park, bool& defer) {
     const float4* material = (const float4*)A.material;
     for (uint32_t l = 0; l < A.n_lights; ++l) {
         const LightArgs& L = A.lights[l];
@@ -156,7 +156,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             } else if (live) {
                 const BoxHit bh = inter_aabb_t<FAST, true>(sh, set_box(S));
                 if (bh.v) {
-                    ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, true, TRI_A10, FAST>(sh, bh, S, defer, tables) : trace_dda<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S, defer, tables);
+                    ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, true, TRI_A10, FAST, GRIDS == 1>(sh, bh, S, defer) : trace_dda<TRIANGLES, true, TRI_A10, FAST, GRIDS == 1>(sh, bh, S, defer);
                     walked = true;
                 }
             }
@@ -191,10 +191,11 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 #ifndef PT_FUSED_WAVES_FAST
 #define PT_FUSED_WAVES_FAST 7   // the optimistic kernel without the grid walk: 72 VGPRs, no scratch (round 1, same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
 #endif
-// GRIDS = false: every set is a single cell (n == 1: the reference's loose spheres and triangles, A10 code.js:399): only the
+// GRIDS = 0    : every set is a single cell (n == 1: the reference's loose spheres and triangles, A10 code.js:399): only the
 //                wave-uniform loops are compiled in.  Without the DDA the register allocator needs 72 VGPRs and no scratch
 //                (80 + 56 B with it): 157.3 -> 152.6 ms on the headline scene.  launch_fused picks it when every set has n == 1.
-// GRIDS = true : sets with n > 1 walk their grid per lane (trace_dda).
+// GRIDS = 1, 2 : sets with n > 1 walk their grid per lane (trace_dda); 1: every cell-offset table is staged in LDS, 2: none is
+//                (a scene whose tables exceed kLdsOffWords).
 // Tried and dropped for GRIDS: packing the rays that hit a mesh's box across the block's four waves through LDS (one wave walks
 // 64 packed rays, three wait at a barrier).  It cuts VALU instructions 4x on those walks and was 30 % SLOWER (cornell_teapot3
 // 1080p x16: 72.2 -> 93.8 ms): the waiting waves keep their registers, so each SIMD is left with too few runnable waves.
@@ -204,23 +205,20 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 #ifndef PT_FUSED_WAVES_GRIDS
 #define PT_FUSED_WAVES_GRIDS 6
 #endif
-template <bool FAST, bool GRIDS>
+template <bool FAST, int GRIDS>
 __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES)) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words) {
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;
     // GRIDS: the cell-offset tables of the grid sets (uint[n^3 + 1] each) are copied into LDS once per block, before any thread
     // leaves: launch_fused gave every set that fits a slot (GridArgs::lds_off).  The primitives themselves stay in memory.
-    const uint32_t* tables = nullptr;
-    if (GRIDS) {
-        __shared__ uint32_t s_tables[kLdsOffWords];
+    if (GRIDS == 1) {
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
-            if (S.n == 1u || S.lds_off == kNoLds) continue;
+            if (S.n == 1u) continue;
             const uint32_t words = S.n * S.n * S.n + 1u;
             const uint32_t* src = (const uint32_t*)S.off;
-            for (uint32_t k = threadIdx.x; k < words; k += 256u) s_tables[S.lds_off + k] = src[k];
+            for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_tables[S.lds_off + k] = src[k];
         }
         __syncthreads();
-        tables = s_tables;
     }
     // Exact kernel in redo mode (`redo_mask`: the bits the optimistic kernel set): one thread per 32-sample word, a loop over its
     // set bits -- no list, no count, no host round trip between the two kernels.  Otherwise: one thread, one sample, one trip.
@@ -299,7 +297,7 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
                 ray.maxt = PT_INF;
             }
         }
-        closest_all<FAST, GRIDS>(A, ray, poi, park, tables, defer);
+        closest_all<FAST, GRIDS>(A, ray, poi, park, defer);
         if (seg == 0) {
             for (uint32_t l = 0; l < A.n_lights; ++l) {  // lightRender (code.cl:600-629), primary segment only
                 if (ray.mint == ray.maxt) continue;
@@ -316,7 +314,7 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
 #endif
             }
         }
-        direct_all<FAST, GRIDS>(A, poi, seed, acc, park, tables, defer);
+        direct_all<FAST, GRIDS>(A, poi, seed, acc, park, defer);
     }
 
     if (FAST && defer) {   // hand the sample to the exact kernel: its inputs stay as they were
@@ -343,20 +341,23 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
     if (!n) return;
     bool grids = false;
     for (uint32_t i = 0; i < a.n_sets; ++i) grids = grids || a.sets[i].n != 1u;
-    FusedArgs b = a;   // LDS slots for the cell-offset tables, first come first served
-    uint32_t used = 0;
+    FusedArgs b = a;   // LDS slots for the cell-offset tables: all of them or none (the walk's table reads are compiled for one address space)
+    uint64_t used = 0;
     for (uint32_t i = 0; i < b.n_sets; ++i) {
         b.sets[i].lds_off = kNoLds;
-        const uint64_t words = (uint64_t)b.sets[i].n * b.sets[i].n * b.sets[i].n + 1u;
-        if (b.sets[i].n > 1u && PT_STAGE_TABLES && used + words <= kLdsOffWords) { b.sets[i].lds_off = used; used += (uint32_t)words; }
+        if (b.sets[i].n > 1u) { b.sets[i].lds_off = (uint32_t)(used < kLdsOffWords ? used : kLdsOffWords); used += (uint64_t)b.sets[i].n * b.sets[i].n * b.sets[i].n + 1u; }
     }
+    const bool staged = PT_STAGE_TABLES && used <= kLdsOffWords;
     const dim3 grid((unsigned)((n + 255) / 256));
+    const size_t lds = staged ? (size_t)used * 4u : 0u;   // dynamic LDS: the staged tables only (what the scene needs, not the 16 KB cap: occupancy)
     if (fast) {
-        if (grids) hipLaunchKernelGGL((k_fusedPass<true, true>), grid, dim3(256), 0, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
-        else hipLaunchKernelGGL((k_fusedPass<true, false>), grid, dim3(256), 0, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
+        if (grids && staged) hipLaunchKernelGGL((k_fusedPass<true, 1>), grid, dim3(256), lds, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
+        else if (grids) hipLaunchKernelGGL((k_fusedPass<true, 2>), grid, dim3(256), 0, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
+        else hipLaunchKernelGGL((k_fusedPass<true, 0>), grid, dim3(256), 0, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
     } else {
-        if (grids) hipLaunchKernelGGL((k_fusedPass<false, true>), grid, dim3(256), 0, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
-        else hipLaunchKernelGGL((k_fusedPass<false, false>), grid, dim3(256), 0, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
+        if (grids && staged) hipLaunchKernelGGL((k_fusedPass<false, 1>), grid, dim3(256), lds, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
+        else if (grids) hipLaunchKernelGGL((k_fusedPass<false, 2>), grid, dim3(256), 0, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
+        else hipLaunchKernelGGL((k_fusedPass<false, 0>), grid, dim3(256), 0, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
     }
 }
 bool fused_fast_available() { return PT_EXACT_FAST_DIV != 0; }

@@ -270,15 +270,29 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     return ch;
 }
 
+// The fused pass stages the cell-offset tables of its grid sets in the block's dynamic LDS (launch_fused sizes it).  The walk reads them
+// through THIS symbol, so the compiler knows the address space and emits ds_read (through a generic pointer selected at run time against
+// the global table it emitted flat_load pairs).  LDS_TABLES is a template parameter for the same reason: k_fusedPass<*, 1> has every
+// table staged, k_fusedPass<*, 2> (a scene whose tables do not fit) reads them all from memory.
+extern __shared__ uint32_t pt_lds_tables[];
+// cell -> [begin, end) of a grid set: one 8-byte LDS read when the table is staged, else two dwords from memory
+template <bool LDS_TABLES>
+PT_DEV void cell_range(const GridArgs& S, const uint32_t* __restrict__ off, uint32_t cell, uint32_t& i, uint32_t& end) {
+    if (LDS_TABLES) {   // compile-time: a run-time choice between the two gets merged back into flat loads
+        const uint32_t k = S.lds_off + cell;
+        i = pt_lds_tables[k];
+        end = pt_lds_tables[k + 1u];
+    } else {
+        i = off[cell];
+        end = off[cell + 1];
+    }
+}
+
 // trace_dda: n > 1, per-lane 3-axis DDA.
-template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false>
-PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer, const uint32_t* lds_tables = nullptr) {
+template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false, bool LDS_TABLES = false>
+PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer) {
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
-    // cell -> [begin, end): from the block's LDS copy of the table when the fused pass staged one (a step of the walk then waits
-    // on an LDS read instead of a vector-memory round trip), else from memory
-    const bool staged = lds_tables != nullptr && S.lds_off != kNoLds;
-    const uint32_t* lt = lds_tables + (staged ? S.lds_off : 0u);
     Hit ch;
     ch.idx = UINT32_MAX;
     ch.t = ray.maxt;
@@ -312,7 +326,7 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     float cmax = cl_min(cl_min(tnx, tny), tnz);
     uint32_t cell = __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx;
     uint32_t i, end;
-    if (staged) { i = lt[cell]; end = lt[cell + 1]; } else { i = off[cell]; end = off[cell + 1]; }
+    cell_range<LDS_TABLES>(S, off, cell, i, end);
     for (;;) {
         bool alive = true;
         while (i == end) {
@@ -340,7 +354,7 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
             cmin = t;
             cmax = cl_min(cl_min(tnx, tny), tnz);
             cell = __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx;
-            if (staged) { i = lt[cell]; end = lt[cell + 1]; } else { i = off[cell]; end = off[cell + 1]; }
+            cell_range<LDS_TABLES>(S, off, cell, i, end);
         }
         if (!alive) break;
         float ti, b = 0.0f, gm = 0.0f;
