@@ -23,7 +23,7 @@
 // {p0, e1 = p1-p0, e2 = p2-p0, n = cross(e2,e1)} -- the ray-independent head of
 // Moeller-Trumbore (A10 code.cl:252-256), computed once with the same fp32 operations, so
 // every value that reaches a ray-dependent operation has the bits it has in the reference.
-#include "pt_trace.hpp"
+#include "pt_trace_coop.hpp"
 
 #ifndef PT_AABB_UNSIGNED_ZERO
 #define PT_AABB_UNSIGNED_ZERO 1   // single-cell sets only (their tmin / tmax / exits are compare-only): see slab1_fast
@@ -98,9 +98,13 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
                 const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(ray, set_box(S));
                 if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, false, TRI_A10, FAST>(ray, bh, S) : trace_cell1<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S);
             }
+        } else if (S.kind == KIND_TRIANGLES) {   // every lane of the wave enters: the tests of the walk are shared (pt_trace_coop.hpp)
+            BoxHit bh = {};
+            if (live) bh = inter_aabb_t<FAST, true>(ray, set_box(S));
+            ch = trace_dda_coop<false, FAST, GRIDS == 1>(live && bh.v, ray, bh, S, defer);
         } else if (live) {
             const BoxHit bh = inter_aabb_t<FAST, true>(ray, set_box(S));
-            if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, false, TRI_A10, FAST, GRIDS == 1>(ray, bh, S, defer) : trace_dda<TRIANGLES, false, TRI_A10, FAST, GRIDS == 1>(ray, bh, S, defer);
+            if (bh.v) ch = trace_dda<SPHERES, false, TRI_A10, FAST, GRIDS == 1>(ray, bh, S, defer);
         }
         if (ch.idx == UINT32_MAX) continue;
         ray.maxt = ch.t;
@@ -153,10 +157,15 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
                         walked = true;
                     }
                 }
+            } else if (S.kind == KIND_TRIANGLES) {
+                BoxHit bh = {};
+                if (live) bh = inter_aabb_t<FAST, true>(sh, set_box(S));
+                walked = live && bh.v;
+                ch = trace_dda_coop<true, FAST, GRIDS == 1>(walked, sh, bh, S, defer);
             } else if (live) {
                 const BoxHit bh = inter_aabb_t<FAST, true>(sh, set_box(S));
                 if (bh.v) {
-                    ch = (S.kind == KIND_SPHERES) ? trace_dda<SPHERES, true, TRI_A10, FAST, GRIDS == 1>(sh, bh, S, defer) : trace_dda<TRIANGLES, true, TRI_A10, FAST, GRIDS == 1>(sh, bh, S, defer);
+                    ch = trace_dda<SPHERES, true, TRI_A10, FAST, GRIDS == 1>(sh, bh, S, defer);
                     walked = true;
                 }
             }
@@ -203,7 +212,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 #define PT_STAGE_TABLES 1
 #endif
 #ifndef PT_FUSED_WAVES_GRIDS
-#define PT_FUSED_WAVES_GRIDS 6
+#define PT_FUSED_WAVES_GRIDS 5   // with the shared-test walk (pt_trace_coop.hpp; 27.5 KB of LDS per block on cornell_teapot3 -> 5 blocks per CU anyway): 6 -> 48.8 ms, 5 -> 43.0, 4 -> 48.1
 #endif
 template <bool FAST, int GRIDS>
 __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES)) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words) {
@@ -216,22 +225,35 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
             if (S.n == 1u) continue;
             const uint32_t words = S.n * S.n * S.n + 1u;
             const uint32_t* src = (const uint32_t*)S.off;
-            for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_tables[S.lds_off + k] = src[k];
+            for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
         }
         __syncthreads();
     }
     // Exact kernel in redo mode (`redo_mask`: the bits the optimistic kernel set): one thread per 32-sample word, a loop over its
     // set bits -- no list, no count, no host round trip between the two kernels.  Otherwise: one thread, one sample, one trip.
+    // GRIDS: the walk shares its triangle tests across the wave (pt_trace_coop.hpp), so every lane stays in to the end: a lane
+    // without a sample of its own (past the end of the tile; no bit left in its redo word) rides along on the tile's last sample
+    // and writes nothing.
     uint64_t base = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t todo = 1u;
     if (!FAST && redo_mask) {
-        if (base >= redo_words) return;
-        todo = redo_mask[base];
+        if (GRIDS) todo = base < redo_words ? redo_mask[base] : 0u;
+        else {
+            if (base >= redo_words) return;
+            todo = redo_mask[base];
+        }
         base *= 32u;
     }
-  for (; todo; todo &= todo - 1u) {
-    const uint64_t lid = base + (uint32_t)__builtin_ctz(todo);
-    if (lid >= n_local) return;
+  for (;; todo &= todo - 1u) {
+    bool valid = todo != 0u;
+    if (GRIDS) { if (__builtin_amdgcn_ballot_w64(valid) == 0ull) break; }
+    else if (!valid) break;
+    uint64_t lid = base + (valid ? (uint32_t)__builtin_ctz(todo) : 0u);
+    if (lid >= n_local) {
+        if (!GRIDS) return;
+        valid = false;
+        lid = n_local - 1u;
+    }
     bool defer = false;
     const uint64_t lpix = lid / A.rpp;
     const uint32_t smp = (uint32_t)(lid - lpix * A.rpp);
@@ -318,9 +340,11 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     }
 
     if (FAST && defer) {   // hand the sample to the exact kernel: its inputs stay as they were
-        atomicOr(&defer_mask[lid >> 5], 1u << (lid & 31u));
-        return;
+        if (valid) atomicOr(&defer_mask[lid >> 5], 1u << (lid & 31u));
+        if (!GRIDS) return;
+        continue;
     }
+    if (!valid) continue;
     A.seeds[lid] = seed;
 #if PT_PARK_LDS
     acc = make_float4(park.get(0), park.get(1), park.get(2), park.get(3));
@@ -345,18 +369,19 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
     uint64_t used = 0;
     for (uint32_t i = 0; i < b.n_sets; ++i) {
         b.sets[i].lds_off = kNoLds;
-        if (b.sets[i].n > 1u) { b.sets[i].lds_off = (uint32_t)(used < kLdsOffWords ? used : kLdsOffWords); used += (uint64_t)b.sets[i].n * b.sets[i].n * b.sets[i].n + 1u; }
+        if (b.sets[i].n > 1u) { b.sets[i].lds_off = kCoopWordsPerBlock + (uint32_t)(used < kLdsOffWords ? used : kLdsOffWords); used += (uint64_t)b.sets[i].n * b.sets[i].n * b.sets[i].n + 1u; }
     }
     const bool staged = PT_STAGE_TABLES && used <= kLdsOffWords;
     const dim3 grid((unsigned)((n + 255) / 256));
-    const size_t lds = staged ? (size_t)used * 4u : 0u;   // dynamic LDS: the staged tables only (what the scene needs, not the 16 KB cap: occupancy)
+    // dynamic LDS: the waves' exchange areas, then the staged tables (what the scene needs, not the 16 KB cap: occupancy)
+    const size_t lds2 = (size_t)kCoopWordsPerBlock * 4u, lds = lds2 + (staged ? (size_t)used * 4u : 0u);
     if (fast) {
         if (grids && staged) hipLaunchKernelGGL((k_fusedPass<true, 1>), grid, dim3(256), lds, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
-        else if (grids) hipLaunchKernelGGL((k_fusedPass<true, 2>), grid, dim3(256), 0, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
+        else if (grids) hipLaunchKernelGGL((k_fusedPass<true, 2>), grid, dim3(256), lds2, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
         else hipLaunchKernelGGL((k_fusedPass<true, 0>), grid, dim3(256), 0, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
     } else {
         if (grids && staged) hipLaunchKernelGGL((k_fusedPass<false, 1>), grid, dim3(256), lds, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
-        else if (grids) hipLaunchKernelGGL((k_fusedPass<false, 2>), grid, dim3(256), 0, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
+        else if (grids) hipLaunchKernelGGL((k_fusedPass<false, 2>), grid, dim3(256), lds2, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
         else hipLaunchKernelGGL((k_fusedPass<false, 0>), grid, dim3(256), 0, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
     }
 }

@@ -274,14 +274,14 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
 // through THIS symbol, so the compiler knows the address space and emits ds_read (through a generic pointer selected at run time against
 // the global table it emitted flat_load pairs).  LDS_TABLES is a template parameter for the same reason: k_fusedPass<*, 1> has every
 // table staged, k_fusedPass<*, 2> (a scene whose tables do not fit) reads them all from memory.
-extern __shared__ uint32_t pt_lds_tables[];
+extern __shared__ uint32_t pt_lds_dyn[];   // [cooperative-walk exchange area (pt_trace_coop.hpp)] [staged tables]: GridArgs::lds_off indexes it
 // cell -> [begin, end) of a grid set: one 8-byte LDS read when the table is staged, else two dwords from memory
 template <bool LDS_TABLES>
 PT_DEV void cell_range(const GridArgs& S, const uint32_t* __restrict__ off, uint32_t cell, uint32_t& i, uint32_t& end) {
     if (LDS_TABLES) {   // compile-time: a run-time choice between the two gets merged back into flat loads
         const uint32_t k = S.lds_off + cell;
-        i = pt_lds_tables[k];
-        end = pt_lds_tables[k + 1u];
+        i = pt_lds_dyn[k];
+        end = pt_lds_dyn[k + 1u];
     } else {
         i = off[cell];
         end = off[cell + 1];
