@@ -87,7 +87,7 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
     const bool fwx = ray.d.x >= 0, fwy = ray.d.y >= 0, fwz = ray.d.z >= 0;   // code.cl:701-705: d >= 0 ? +1, n : -1, -1
     float cmin = 0.0f, cmax = 0.0f;
     uint32_t i = 0u, end = 0u;
-    bool alive = want;
+    bool alive = want && !(bh.tmin >= ray.maxt);
     if (want) {
         bool dfr = false;
         const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, dfr);
@@ -128,7 +128,9 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
                 sz += fwz ? 1 : -1;
                 out = t >= bh.tmax || sz == (fwz ? nn : -1);
             }
-            if (out) { alive = false; break; }
+            // ... or the cell starts at or beyond the ray's end: a hit needs cmin <= t < maxt, and cmin only grows from here
+            // (the reference walks on to the grid's far side rejecting every hit; nothing it computes there survives)
+            if (out || t >= ray.maxt) { alive = false; break; }
             cmin = t;
             cmax = cl_min(cl_min(tnx, tny), tnz);
             cell_range<LDS_TABLES>(S, off, __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx, i, end);

@@ -272,6 +272,52 @@ def test_medium_frames_match_oracle(ctx, pkg, name):
     fr.release()
 
 
+def _regrid_mesh(m, n):
+    """A packed A10 mesh (cell-sorted, duplicated triangles) re-binned at another grid resolution by the restatement of the reference
+    host's splitMeshData (tests/test_grid_build.py).  The triangle set is the mesh's distinct (position, normal) records."""
+    from test_grid_build import expected_grid
+    pos = np.asarray(m["pos"], np.float32).reshape(-1, 12)
+    nor = np.asarray(m["normal"], np.float32).reshape(-1, 12)
+    _, first = np.unique(np.concatenate([pos, nor], axis=1), axis=0, return_index=True)
+    first.sort()
+    pos, nor = pos[first], nor[first]
+    tri = pos.reshape(-1, 3, 4)[:, :, :3].reshape(-1, 9).astype(np.float64)
+    b = np.asarray(m["bounds"], np.float64)
+    off, order = expected_grid(1, tri, [b[0], b[1], b[2], b[4], b[5], b[6]], n)
+    return dict(m, nslabs=n, box=off.tolist(), pos=pos[order].ravel().tolist(), normal=nor[order].ravel().tolist())
+
+
+@pytest.mark.parametrize("n", [2, 17, 24])
+def test_teapot_at_other_grid_resolutions(ctx, pkg, n):
+    """cornell_teapot3 with its teapot re-binned: n = 2 puts hundreds of triangles in a cell (the shared-test walk lays one cell out over
+    many 64-pair rounds), n = 17 and 24 have cell-offset tables that do not fit the LDS budget (kLdsOffWords: the fused pass then reads
+    every table from memory, k_fusedPass<*, 2>).  Fused pass (both modes) and kernel-by-kernel path against the CPU oracle."""
+    from raytracing_amd.pyhost import render
+    fx, sc0 = load_fixture("cornell_teapot3_32x24_r4")
+    meshes = [_regrid_mesh(sc0.d["meshes"][0], n)] + list(sc0.d["meshes"][1:])
+    sc = _variant(sc0, width=96, height=54, rays_per_pixel=4, meshes=meshes)
+    seeds = A.make_seeds(sc.total_rays, seed_base=n)
+    orc = A.load_oracle()
+    st = A.PassState(sc, seeds)
+    A.run_pass(orc, sc, st)
+    assert (st.pois["matId"] == sc.d["meshes"][0]["matid"]).mean() > 0.02   # the teapot is in the picture
+    for exact_only in (False, True):
+        ctx.set_exact_only(exact_only)
+        fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+        fr.execute_render()
+        assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(st.acu)), f"fused, exact_only={exact_only}"
+        assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
+        assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), st.pixel)
+        fr.release()
+    ctx.set_exact_only(False)
+    gr = render.GranularRenderer(ctx, sc, seeds=seeds)
+    gr.execute_render()
+    got = snapshot(gr)
+    assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds), "granular"
+    assert np.array_equal(got["pois"]["matId"], st.pois["matId"])
+    gr.release()
+
+
 @pytest.mark.parametrize("name", ["cornell_16x12_r9", "cornell_teapot3_32x24_r4"])
 def test_first_pass_initialises_the_accumulator(ctx, pkg, name):
     """mirt_render_first_pass = initAcu folded into the pass: over an accumulator full of junk it gives what zeroing + a normal pass
