@@ -30,11 +30,18 @@ enum TriRule { TRI_A10 = 0, TRI_A07 = 1, TRI_A04 = 2 };
 // the guards guarantee (ray_guard() on the ray side, GridArgs::fast_ok on the geometry side).  A lane whose ray fails the guard
 // still runs this code -- on values nobody will read: the optimistic kernel marks that sample `deferred` and the exact kernel
 // (FAST = false, true divisions everywhere) recomputes it from its untouched seed and accumulator (pt_kernels_fused.hip).
-template <int RULE = TRI_A10, bool FAST = false>
+#ifndef PT_UNIFORM_CULL
+#define PT_UNIFORM_CULL 0
+#endif
+// WAVE_CULL (the wave-uniform loops: all lanes hold the SAME triangle): when the triangle faces away from every lane's ray
+// (div <= 0 in all of them: coherent primary and shadow rays against half of a closed room's walls) the rest of the test is skipped for the
+// wave -- the reference's first early-out (code.cl:259), taken when the whole wave takes it.
+template <int RULE = TRI_A10, bool FAST = false, bool WAVE_CULL = false>
 PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const float4 B, const float4 C,
                      float& t_out, float& beta_out, float& gamma_out) {
     const f3 p0 = mk3(A.x, A.y, A.z), e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z), n = mk3(A.w, B.w, C.w);
     float div = dot3(n, d);
+    if (WAVE_CULL && __builtin_amdgcn_ballot_w64(!(div <= 0)) == 0ull) { t_out = 0.0f; beta_out = 0.0f; gamma_out = 0.0f; return false; }
     float idiv;
     if (FAST) idiv = rcp_refined(div);   // div <= 0 (incl. 0 -> NaN) and NaN lanes are rejected below whatever idiv is
     else idiv = 1.0f / div;
@@ -255,7 +262,7 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         if (KIND == SPHERES) {
             hit = sph_test(ray.o, ray.d, sr, cmin, cmax, p[0], ti);
         } else {
-            hit = tri_test<RULE, FAST>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, gm);
+            hit = tri_test<RULE, FAST, PT_UNIFORM_CULL != 0>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, gm);
         }
         const bool better = (int)!done & (int)hit & (int)(ti < ch.t);
         ch.t = better ? ti : ch.t;          // selects, not a branch: some lane of an incoherent wave almost always hits

@@ -152,12 +152,8 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
             wave_fence();
             const uint32_t mark = wave_scan_max(CW_MINE(CW_OWN));
             const uint32_t p = base + lane;
-            bool ok = false;
-            unsigned long long mk = 0ull;
-            uint32_t o = 0u;
-            float tt = 0.0f, bb = 0.0f, gg = 0.0f;
             if (p < total && mark != 0u) {
-                o = mark - 1u;
+                const uint32_t o = mark - 1u;
                 const uint32_t prim = CW_OF(CW_IBX, o) + p;
                 if (prim < nslots) {
                     const f3 ro = mk3(__uint_as_float(CW_OF(CW_OX, o)), __uint_as_float(CW_OF(CW_OY, o)), __uint_as_float(CW_OF(CW_OZ, o)));
@@ -165,22 +161,22 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
                     const float omax = __uint_as_float(CW_OF(CW_MAXT, o));
                     const float ocmin = __uint_as_float(CW_OF(CW_CMIN, o)), ocmax = __uint_as_float(CW_OF(CW_CMAX, o));
                     const float4* __restrict__ q = prims + 3u * (size_t)prim;
-                    ok = tri_test<TRI_A10, FAST>(ro, rd, ocmin, ocmax, q[0], q[1], q[2], tt, bb, gg) && tt < omax;
-                    if (ok) {
+                    float tt, bb, gg;
+                    if (tri_test<TRI_A10, FAST>(ro, rd, ocmin, ocmax, q[0], q[1], q[2], tt, bb, gg) && tt < omax) {
                         if (ANY) keys[o] = 0ull;
                         else {
-                            mk = ((unsigned long long)t_key(tt) << 32) | prim;
+                            const unsigned long long mk = ((unsigned long long)t_key(tt) << 32) | prim;
                             __hip_atomic_fetch_min(&keys[o], mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            // the pair that holds its owner's minimum hands over its own t / beta / gamma bits.  Every lane's minimum of
+                            // this round is in before any lane's read below (one wave: the LDS runs its instructions in order)
+                            wave_fence();
+                            if (keys[o] == mk) {
+                                CW_OF(CW_T, o) = __float_as_uint(tt);
+                                CW_OF(CW_BETA, o) = __float_as_uint(bb);
+                                CW_OF(CW_GAMMA, o) = __float_as_uint(gg);
+                            }
                         }
                     }
-                }
-            }
-            if (!ANY) {   // the pair that holds its owner's minimum hands over its own t / beta / gamma bits
-                wave_fence();
-                if (ok && keys[o] == mk) {
-                    CW_OF(CW_T, o) = __float_as_uint(tt);
-                    CW_OF(CW_BETA, o) = __float_as_uint(bb);
-                    CW_OF(CW_GAMMA, o) = __float_as_uint(gg);
                 }
             }
         }

@@ -233,7 +233,7 @@ def main():
     flops = None if fps_table is None else fps_table.get(args.bounces, fps_table[5] * (1 + args.bounces) / 6.0)
     valu_tf = (flops or 0.0) * local_samples / (fused_ms * 1e-3) / 1e12
     has_grids = any(m["nslabs"] > 1 for m in sc.d.get("meshes", [])) or sc.d.get("n_slabs", 1) > 1
-    kernel_name = "pt::k_fusedPass<true,true>" if has_grids else "pt::k_fusedPass<true,false>"
+    kernel_name = "pt::k_fusedPass<true,1>" if has_grids else "pt::k_fusedPass<true,0>"   # <optimistic, grids: 0 none / 1 tables in LDS / 2 in memory>
     hbm_gbs = BYTES_PER_SAMPLE_FUSED * local_samples / (fused_ms * 1e-3) / 1e9
 
     default_wl = (world == 1 and args.scene == "cornell" and (sc.width, sc.height, sc.rpp, args.bounces) == (1920, 1080, 256, 8))
