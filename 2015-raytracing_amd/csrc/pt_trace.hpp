@@ -337,7 +337,9 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     for (;;) {
         bool alive = true;
         while (i == end) {
-            // close the cell: a hit inside it ends the walk (code.cl:768-771); else step the axis whose plane was reached.
+            // close the cell: a hit inside it ends the walk (code.cl:768-771); else step the axis whose plane was reached.  The walk
+            // also ends where the next cell would start at or beyond the ray's end (t >= maxt): a hit needs cmin <= t < maxt and cmin only
+            // grows, so nothing the reference computes past that point survives.
             // Kept as the reference's if / else-if / else chain: the walk is VALU-bound at a quarter of the lanes, and the
             // branches cost scalar instructions, which are not the bottleneck (selects instead: 72.2 -> 77.6 ms on cornell_teapot3)
             if (ch.idx != UINT32_MAX) { alive = false; break; }
@@ -346,17 +348,17 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
                 tnx += dtx;
                 const bool fwd = ray.d.x >= 0;
                 sx += fwd ? 1 : -1;
-                if (t >= bh.tmax || sx == (fwd ? nn : -1)) { alive = false; break; }
+                if (t >= bh.tmax || t >= ray.maxt || sx == (fwd ? nn : -1)) { alive = false; break; }
             } else if (t == tny) {
                 tny += dty;
                 const bool fwd = ray.d.y >= 0;
                 sy += fwd ? 1 : -1;
-                if (t >= bh.tmax || sy == (fwd ? nn : -1)) { alive = false; break; }
+                if (t >= bh.tmax || t >= ray.maxt || sy == (fwd ? nn : -1)) { alive = false; break; }
             } else {
                 tnz += dtz;
                 const bool fwd = ray.d.z >= 0;
                 sz += fwd ? 1 : -1;
-                if (t >= bh.tmax || sz == (fwd ? nn : -1)) { alive = false; break; }
+                if (t >= bh.tmax || t >= ray.maxt || sz == (fwd ? nn : -1)) { alive = false; break; }
             }
             cmin = t;
             cmax = cl_min(cl_min(tnx, tny), tnz);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# profiles/round_final.sh <tag> -- the round's closing measurement on the GPU box (through gpurun): full GPU test suite, the default
+# bench line, the grid-scene bench line, every fixture scene, the kernel-by-kernel path (with and without command-stream fusion),
+# then the rocprofv3 passes of the default bench (run_profile.sh) and the SQ counters of the grid scene (scene_pmc.sh).
+set -uo pipefail
+TAG="${1:-final}"
+OUT="gpurun_out/${TAG}"; mkdir -p "${OUT}"
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > "${OUT}/gpu_tests.txt" 2>&1 || { tail -20 "${OUT}/gpu_tests.txt"; exit 21; }
+tail -1 "${OUT}/gpu_tests.txt"
+timeout -k 10 600 python bench.py > "${OUT}/bench.json" 2> "${OUT}/bench.err" || exit 22
+timeout -k 10 300 python bench.py --scene cornell_teapot3 --no-cpu > "${OUT}/bench_teapot3.json" 2> "${OUT}/bench_teapot3.err" || exit 23
+timeout -k 10 300 python profiles/scene_bench.py > "${OUT}/scene_bench.txt" 2>&1 || exit 24
+timeout -k 10 300 python profiles/granular_bench.py > "${OUT}/granular.txt" 2>&1 || exit 25
+timeout -k 10 300 python profiles/grid_split.py > "${OUT}/grid_split.txt" 2>&1 || exit 26
+timeout -k 10 900 bash profiles/run_profile.sh "${TAG}" > "${OUT}/run_profile.log" 2>&1 || exit 27
+timeout -k 10 600 bash profiles/scene_pmc.sh cornell_teapot3_32x24_r4 "${TAG}_teapot3" > "${OUT}/teapot3_pmc.txt" 2>&1 || exit 28
+echo "all done"
