@@ -208,6 +208,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 // Tried and dropped for GRIDS: packing the rays that hit a mesh's box across the block's four waves through LDS (one wave walks
 // 64 packed rays, three wait at a barrier).  It cuts VALU instructions 4x on those walks and was 30 % SLOWER (cornell_teapot3
 // 1080p x16: 72.2 -> 93.8 ms): the waiting waves keep their registers, so each SIMD is left with too few runnable waves.
+// What pays instead is sharing the TESTS inside each wave, no barrier, no idle wave: pt_trace_coop.hpp (65.4 -> 40.2 ms).
 #ifndef PT_STAGE_TABLES
 #define PT_STAGE_TABLES 1
 #endif
