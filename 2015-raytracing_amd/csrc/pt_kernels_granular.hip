@@ -4,7 +4,7 @@
 // (include/mirt.h).  One work-item per ray (or per pixel for initTrace / copyToPixel).
 // These are HBM-bound by construction (every stage round-trips the ray state through
 // memory, ~4.2 KB/sample on cornell.xml); the fast path is pt_kernels_fused.hip.
-#include "pt_trace.hpp"
+#include "pt_trace_coop.hpp"
 
 namespace pt {
 
@@ -279,6 +279,66 @@ __global__ void __launch_bounds__(256) k_anyhit(uint32_t total, RayAoS* shadow, 
                 }
             }
         }
+    }
+    pr[threadIdx.x] = mr;
+    flush_structs<3>(sray, pr, shadow, blockIdx.x * 256u, lim);
+}
+
+// meshTrace / triangleTrace and triangleShadowTrace over a grid with n > 1: the same kernels, with the walk whose triangle tests the wave
+// shares (pt_trace_coop.hpp).  Every lane stays in (a lane without a live ray walks nothing and tests for the others); 16 KB of dynamic
+// LDS per block for the waves' exchange rows.  Same per-ray cells, primitives, windows and results as the per-lane walk above.
+__global__ void __launch_bounds__(256) k_closestMesh(uint32_t total, PoiAoS* pois, RayAoS* rays, const float4* prims, const float4* normals,
+                                                      const uint32_t* matid, uint32_t mesh_matid, const uint32_t* off, Box8 bound8, uint32_t n, uint32_t gsz) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = id < gsz && id < total;
+    Ray ray = {};
+    BoxHit bh = {};
+    bool want = false;
+    if (mine) {
+        ray = load_ray(&rays[id]);
+        if (!(ray.mint == ray.maxt)) {
+            bh = inter_aabb(ray, mk_box(bound8));
+            want = bh.v;
+        }
+    }
+    bool unused = false;
+    const Hit ch = trace_dda_coop<COOP_CLOSEST, false, false>(want, ray, bh, mk_set(prims, off, bound8, n, 0u), unused);
+    if (!want || ch.idx == UINT32_MAX) return;
+    rays[id].maxt = ch.t;
+    const f3 p = fma3(ch.t, ray.d, ray.o);   // getPoint, code.cl:87
+    const float4* nn = normals + 3u * (size_t)ch.idx;
+    const float w = 1.0f - ch.beta - ch.gamma;                         // code.cl:409-411
+    const f3 nrm = norm3(fma3(ch.gamma, ld3(nn[2]), fma3(w, ld3(nn[0]), scl3(ch.beta, ld3(nn[1])))));
+    PoiAoS* pp = &pois[id];
+    float4* q = reinterpret_cast<float4*>(pp);
+    q[0] = make_float4(p.x, p.y, p.z, 0.0f);
+    q[1] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+    pp->matId = (int32_t)(matid ? matid[ch.idx] : mesh_matid);
+}
+
+__global__ void __launch_bounds__(256) k_anyhitMesh(uint32_t total, RayAoS* shadow, const float4* prims, const uint32_t* off, Box8 bound8, uint32_t n, uint32_t gsz) {
+    __shared__ float4 sray[256 * 3];
+    __shared__ uint8_t pr[256];
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lim = gsz < total ? gsz : total;
+    Ray sh = {};
+    BoxHit bh = {};
+    bool want = false;
+    if (id < lim) {
+        sh = load_ray(&shadow[id]);
+        if (!(sh.mint == sh.maxt)) {
+            bh = inter_aabb(sh, mk_box(bound8));
+            want = bh.v;
+        }
+    }
+    bool unused = false;
+    const Hit ch = trace_dda_coop<COOP_ANY_FIRST, false, false>(want, sh, bh, mk_set(prims, off, bound8, n, 0u), unused);
+    uint8_t mr = 0;
+    if (want && ch.idx != UINT32_MAX) {
+        sh.mint = ch.t;
+        sh.maxt = ch.t;
+        put_ray(sray, sh);
+        mr = kRayAll;
     }
     pr[threadIdx.x] = mr;
     flush_structs<3>(sray, pr, shadow, blockIdx.x * 256u, lim);
@@ -564,6 +624,9 @@ void launch_closest(hipStream_t s, int kind, uint32_t total, void* pois, void* r
     if (kind == SPHERES)
         hipLaunchKernelGGL(k_closest<SPHERES>, grid1(gsz), dim3(256), 0, s, total, (PoiAoS*)pois, (RayAoS*)rays, (const float4*)prims,
                            (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, exit_far, gsz);
+    else if (n > 1u)
+        hipLaunchKernelGGL(k_closestMesh, grid1(gsz), dim3(256), (size_t)kCoopWordsPerBlock * 4u, s, total, (PoiAoS*)pois, (RayAoS*)rays, (const float4*)prims,
+                           (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, gsz);
     else
         hipLaunchKernelGGL(k_closest<TRIANGLES>, grid1(gsz), dim3(256), 0, s, total, (PoiAoS*)pois, (RayAoS*)rays, (const float4*)prims,
                            (const float4*)normals, (const uint32_t*)matid, mesh_matid, (const uint32_t*)off, mk8(bound), n, exit_far, gsz);
@@ -573,6 +636,8 @@ void launch_anyhit(hipStream_t s, int kind, uint32_t total, void* shadow, const 
     if (!gsz) return;
     if (kind == SPHERES)
         hipLaunchKernelGGL(k_anyhit<SPHERES>, grid1(gsz), dim3(256), 0, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, exit_far, gsz);
+    else if (n > 1u)
+        hipLaunchKernelGGL(k_anyhitMesh, grid1(gsz), dim3(256), (size_t)kCoopWordsPerBlock * 4u, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, gsz);
     else
         hipLaunchKernelGGL(k_anyhit<TRIANGLES>, grid1(gsz), dim3(256), 0, s, total, (RayAoS*)shadow, (const float4*)prims, (const uint32_t*)off, mk8(bound), n, exit_far, gsz);
 }

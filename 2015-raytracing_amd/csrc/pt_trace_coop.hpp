@@ -13,7 +13,8 @@
 // reference's nested loops (A10 code.cl:937-1070, 1195-1321); only WHO evaluates a test and in which order changes.  Order does not
 // matter: inside a cell the reference keeps the hit with the smallest t, the first one among equals (strict <, code.cl:1017-1026) --
 // the minimum of (t, index) -- and closes the walk at the first cell that produced one.  For shadow rays only "was anything hit with
-// t < maxt" survives the kernel (sceneRender compares mint with maxt, code.cl:1339), so any hit will do.
+// t < maxt" survives the fused kernel (sceneRender compares mint with maxt, code.cl:1339), so any hit will do there; the
+// kernel-by-kernel path stores the shadow Ray and asks for the first hit in list order: the minimum of the index alone.
 // t values are compared through the usual order-preserving map of IEEE bits to unsigned, after t + 0 (a -0 and a +0 are the same
 // distance to the reference's <); the winner's own t / beta / gamma bits travel through three more LDS words.
 //
@@ -63,8 +64,16 @@ PT_DEV uint32_t t_key(float t) {
     return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
 }
 
-template <bool ANY, bool FAST, bool LDS_TABLES>
+// What a walk reports:
+//   COOP_CLOSEST   the closest hit of the first cell that has one: index, t, beta, gamma                       (code.cl:937-1070)
+//   COOP_ANY       whether anything is hit (idx != UINT32_MAX); t is not delivered -- the fused pass only asks "blocked?"
+//   COOP_ANY_FIRST the reference's shadow loop to the letter: the FIRST primitive of the cell, in list order, that is hit, and its t
+//                  (code.cl:1195-1321 leaves mint = maxt = that t in the shadow Ray, which the kernel-by-kernel path stores)
+enum CoopMode { COOP_CLOSEST = 0, COOP_ANY = 1, COOP_ANY_FIRST = 2 };
+
+template <int MODE, bool FAST, bool LDS_TABLES>
 PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer) {
+    constexpr bool ANY = MODE == COOP_ANY;
     Hit ch;
     ch.idx = UINT32_MAX;
     ch.t = ray.maxt;
@@ -165,7 +174,8 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
                     if (tri_test<TRI_A10, FAST>(ro, rd, ocmin, ocmax, q[0], q[1], q[2], tt, bb, gg) && tt < omax) {
                         if (ANY) keys[o] = 0ull;
                         else {
-                            const unsigned long long mk = ((unsigned long long)t_key(tt) << 32) | prim;
+                            // COOP_ANY_FIRST: the lowest primitive index wins whatever its t
+                            const unsigned long long mk = MODE == COOP_ANY_FIRST ? (unsigned long long)prim : (((unsigned long long)t_key(tt) << 32) | prim);
                             __hip_atomic_fetch_min(&keys[o], mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             // the pair that holds its owner's minimum hands over its own t / beta / gamma bits.  Every lane's minimum of
                             // this round is in before any lane's read below (one wave: the LDS runs its instructions in order)
@@ -193,8 +203,10 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
             ch.idx = (uint32_t)k;
             if (!ANY) {
                 ch.t = __uint_as_float(CW_MINE(CW_T));
-                ch.beta = __uint_as_float(CW_MINE(CW_BETA));
-                ch.gamma = __uint_as_float(CW_MINE(CW_GAMMA));
+                if (MODE == COOP_CLOSEST) {
+                    ch.beta = __uint_as_float(CW_MINE(CW_BETA));
+                    ch.gamma = __uint_as_float(CW_MINE(CW_GAMMA));
+                }
             }
         }
     }

@@ -9,12 +9,17 @@ import __graft_entry__ as g
 g.load_package()
 from raytracing_amd.pyhost import mirt, render, scene
 import a10_pass as A, ref_gpu as G
-base = scene.PackedScene(open(os.path.join(ROOT, "tests", "golden", "scene_cornell_1920x1080_r256.json")).read())
+# SCENE=<fixture name> (e.g. cornell_teapot3_32x24_r4): another A10 scene the fixtures carry, re-sized; default the headline scene
+if os.environ.get("SCENE"):
+    base = scene.PackedScene(bytes(np.load(os.path.join(ROOT, "tests", "golden", os.environ["SCENE"] + ".npz"))["scene_json"]).decode())
+else:
+    base = scene.PackedScene(open(os.path.join(ROOT, "tests", "golden", "scene_cornell_1920x1080_r256.json")).read())
 ctx = mirt.Context(0)
 k = G.GpuRefKernels()
 for rpp in [int(x) for x in os.environ.get("RPPS", "16,64").split(",")]:
     ps = base.resized(1920, 1080, rpp)
-    ps.cam = base.cam.copy()
+    if not os.environ.get("SCENE"):
+        ps.cam = base.cam.copy()
     sc = A.Scene(ps.d)
     n, npix = sc.total_rays, sc.width * sc.height
     class St: pass
@@ -32,6 +37,13 @@ for rpp in [int(x) for x in os.environ.get("RPPS", "16,64").split(",")]:
             A.run_pass(k, sc, st, bounces=bounces, init_acu=False)
         G.chk(G.hip().hipDeviceSynchronize(), "sync")
         dt = (time.perf_counter() - t0) / reps
+        gr = render.GranularRenderer(ctx, ps)                   # our kernel-by-kernel path, same launch structure
+        gr.execute_render(bounces=bounces); ctx.finish()
+        t2 = time.perf_counter()
+        for _ in range(reps): gr.execute_render(bounces=bounces)
+        ctx.finish()
+        dg = (time.perf_counter() - t2) / reps
+        gr.release()
         fr = render.FusedRenderer(ctx, ps, want_radiance=False)
         fr.execute_render(bounces=bounces); ctx.finish()
         t1 = time.perf_counter()
@@ -40,6 +52,6 @@ for rpp in [int(x) for x in os.environ.get("RPPS", "16,64").split(",")]:
         df = (time.perf_counter() - t1) / reps
         fr.release()
         print(json.dumps({"rpp": rpp, "bounces": bounces, "samples": n, "reference_kernels_ms_per_pass": round(dt * 1e3, 2), "reference_Msamples_s": round(n / dt / 1e6, 1),
-                          "mirt_fused_ms_per_pass": round(df * 1e3, 2), "mirt_fused_Msamples_s": round(n / df / 1e6, 1), "speedup": round(dt / df, 2)}), flush=True)
+                          "mirt_kernel_by_kernel_ms_per_pass": round(dg * 1e3, 2), "mirt_fused_ms_per_pass": round(df * 1e3, 2), "mirt_fused_Msamples_s": round(n / df / 1e6, 1), "speedup": round(dt / df, 2)}), flush=True)
     for b in (st.rays, st.pois, st.shadow, st.acu, st.seeds, st.pixel): b.free()
 k.release(); ctx.destroy()
