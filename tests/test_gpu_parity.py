@@ -318,6 +318,58 @@ def test_teapot_at_other_grid_resolutions(ctx, pkg, n):
     gr.release()
 
 
+def _regrid_loose_sets(d, n):
+    """The scene's loose spheres and triangles binned at n_slabs = n (the reference host uses 1 for them, A10 code.js:399, but its kernels
+    take any): cell lists by the restatement of splitSphereData / splitTriangleData over the packed primitives."""
+    from test_grid_build import expected_grid
+    out = {"n_slabs": n}
+    if d["n_spheres"]:
+        sph = np.asarray(d["spheres"], np.float32).reshape(-1, 4)
+        b = np.asarray(d["sphere_bounds"], np.float64)
+        cr = np.concatenate([sph[:, :3].astype(np.float64), np.sqrt(sph[:, 3:4].astype(np.float64))], axis=1)   # packed (c, r^2)
+        off, order = expected_grid(0, cr, [b[0], b[1], b[2], b[4], b[5], b[6]], n)
+        out.update(spheres=sph[order].ravel().tolist(), s_matid=np.asarray(d["s_matid"])[order].tolist(), s_box=off.tolist(), n_spheres=len(order))
+    if d["n_triangles"]:
+        pos = np.asarray(d["t_pos"], np.float32).reshape(-1, 12)
+        nor = np.asarray(d["t_normal"], np.float32).reshape(-1, 12)
+        b = np.asarray(d["triangle_bounds"], np.float64)
+        tri = pos.reshape(-1, 3, 4)[:, :, :3].reshape(-1, 9).astype(np.float64)
+        off, order = expected_grid(1, tri, [b[0], b[1], b[2], b[4], b[5], b[6]], n)
+        out.update(t_pos=pos[order].ravel().tolist(), t_normal=nor[order].ravel().tolist(), t_matid=np.asarray(d["t_matid"])[order].tolist(),
+                   t_box=off.tolist(), n_triangles=len(order))
+    return out
+
+
+@pytest.mark.parametrize("name,n", [("basic_32x24_r4", 3), ("triangles_32x24_r4", 2), ("cornell_32x24_r4", 4), ("own_gems_48x36_r4", 3)])
+def test_loose_spheres_and_triangles_in_grids(ctx, pkg, name, n):
+    """sphereTrace / triangleTrace and their shadow kernels with n_slabs > 1: sphere sets walk the per-lane DDA, loose-triangle sets
+    (per-primitive material ids) the shared-test walk, next to meshes with their own grids where the scene has them."""
+    from raytracing_amd.pyhost import render
+    fx, sc0 = load_fixture(name)
+    sc = _variant(sc0, width=80, height=45, rays_per_pixel=4, **_regrid_loose_sets(sc0.d, n))
+    seeds = A.make_seeds(sc.total_rays, seed_base=7 * n)
+    orc = A.load_oracle()
+    st = A.PassState(sc, seeds)
+    A.run_pass(orc, sc, st)
+    assert (st.pois["matId"] >= 0).mean() > 0.1
+    for exact_only in (False, True):
+        ctx.set_exact_only(exact_only)
+        fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+        fr.execute_render()
+        assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(st.acu)), f"fused, exact_only={exact_only}"
+        assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
+        fr.release()
+    ctx.set_exact_only(False)
+    gr = render.GranularRenderer(ctx, sc, seeds=seeds)
+    gr.execute_render()
+    got = snapshot(gr)
+    assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds), "granular"
+    assert np.array_equal(got["pois"]["matId"], st.pois["matId"])
+    for f in ("mint", "maxt"):
+        assert np.array_equal(bits(got["shadow"][f]), bits(st.shadow[f])), f"shadow.{f}"
+    gr.release()
+
+
 @pytest.mark.parametrize("name", ["cornell_16x12_r9", "cornell_teapot3_32x24_r4"])
 def test_first_pass_initialises_the_accumulator(ctx, pkg, name):
     """mirt_render_first_pass = initAcu folded into the pass: over an accumulator full of junk it gives what zeroing + a normal pass
