@@ -1197,6 +1197,18 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     for (int k = 0; k < 3; ++k)
         if (!(g->bounds[k] <= g->bounds[4 + k])) o->fast_ok = 0;
     if (tri && !g->prims->prep_sane) o->fast_ok = 0;
+    // the walk's wave-uniform quotients, once, in the arithmetic the kernel would use: fp32, correctly rounded
+    o->walk_ok = 1;
+    for (int k = 0; k < 3; ++k) {
+        const float span = g->bounds[4 + k] - g->bounds[k];
+        const float delta = span / (float)g->n_slabs;
+        o->delta[k] = delta;
+        o->rdelta[k] = 1.0f / delta;
+        const float as = std::fabs(span), ad = std::fabs(delta);
+        const bool span_in = span == 0.0f || (as >= 8.6736174e-19f && as <= 1.1529215e18f);   // 0 | 2^-60 .. 2^60 (pt_trace.hpp num_window)
+        const bool delta_in = ad >= 9.094947e-13f && ad <= 1.0995116e12f;                      // 2^-40 .. 2^40       (den_window)
+        if (!(span_in && delta_in)) o->walk_ok = 0;
+    }
     return MIRT_OK;
 }
 

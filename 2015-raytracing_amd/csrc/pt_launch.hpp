@@ -48,6 +48,10 @@ struct GridArgs {            // one cell-sorted primitive set, device pointers
                              // in [2^-30, 2^20]; for triangles every plane-normal component is 0 or in [2^-40, 2^40]
     uint32_t lds_off;        // n > 1, fused pass: dword index of this set's cell-offset table inside the block's LDS copy, or
                              // kNoLds when the tables of the scene do not fit (launch_fused assigns it)
+    float delta[3], rdelta[3]; // n > 1, optimistic kernel: the cell width per axis (hi - lo) / n and its reciprocal, both correctly rounded --
+    uint32_t walk_ok;        // what every lane would compute for itself from wave-uniform inputs (pt_trace.hpp axis_setup_t).  walk_ok: the
+                             // widths and spans sit inside the windows in which the kernel's 3-operation divisions are exact; a lane that
+                             // walks a set without it hands its sample to the exact kernel
     uint32_t exit_is_far_face; // n == 1 only: lo + 1*((hi-lo)/1) == hi and lo + 0*((hi-lo)/1) == lo hold bitwise on all three
                              // axes (checked on the host), so the single cell's exit t equals the AABB slab's far t
 };

@@ -196,15 +196,15 @@ PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, co
 // here, per lane, and a lane outside the windows marks its sample for the exact kernel.
 PT_DEV bool num_window(float v) { const float a = __builtin_fabsf(v); return v == 0.0f || (a >= 8.6736174e-19f && a <= 1.1529215e18f); }   // 0 | 2^-60 .. 2^60
 PT_DEV bool den_window(float v) { const float a = __builtin_fabsf(v); return a >= 9.094947e-13f && a <= 1.0995116e12f; }                    // 2^-40 .. 2^40
+// The slab width delta = (hi - lo) / n and 1 / delta depend on the set alone: the host computes them once (GridArgs::delta / rdelta,
+// correctly rounded, which is what div_exact3 / rcp_refined give inside their windows; GridArgs::walk_ok says the windows hold).
 template <bool FAST>
-PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint32_t n, bool& defer) {
+PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint32_t n, float delta, float rdelta, bool& defer) {
     if (!FAST) return axis_setup(o, d, tmin, lo, hi, n);
     Axis a;
     const float x = cl_fma(tmin, d, o);                    // code.cl:698
-    const float fn = (float)n, span = hi - lo;
-    const float delta = div_exact3(span, fn, rcp_refined(fn));
     const float num0 = x - lo;
-    a.slab = f2i(div_exact3(num0, delta, rcp_refined(delta)));
+    a.slab = f2i(div_exact3(num0, delta, rdelta));
     if (a.slab < 0) a.slab = 0;
     if ((uint32_t)a.slab >= n) a.slab = (int)(n - 1u);
     const bool fwd = d >= 0;
@@ -215,7 +215,7 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     const float xnext = cl_fma((float)(a.slab + (fwd ? 1 : 0)), delta, lo);   // code.cl:706
     const float num1 = xnext - o;
     a.tnext = div_exact3(num1, d, rd);
-    defer = defer || !(num_window(span) && num_window(num0) && den_window(delta) && num_window(num1));
+    defer = defer || !(num_window(num0) && num_window(num1));
     return a;
 }
 
@@ -312,9 +312,10 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     float tnx, tny, tnz, dtx, dty, dtz;
     int sx, sy, sz;
     {
-        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, defer);
-        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, defer);
-        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, defer);
+        if (FAST) defer = defer || S.walk_ok == 0u;
+        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, S.delta[0], S.rdelta[0], defer);
+        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, S.delta[1], S.rdelta[1], defer);
+        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, S.delta[2], S.rdelta[2], defer);
         tnx = ax.tnext; tny = ay.tnext; tnz = az.tnext;
         dtx = ax.dt; dty = ay.dt; dtz = az.dt;
         sx = ax.slab; sy = ay.slab; sz = az.slab;

@@ -98,10 +98,10 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
     uint32_t i = 0u, end = 0u;
     bool alive = want && !(bh.tmin >= ray.maxt);
     if (want) {
-        bool dfr = false;
-        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, dfr);
-        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, dfr);
-        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, dfr);
+        bool dfr = FAST && S.walk_ok == 0u;
+        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, S.delta[0], S.rdelta[0], dfr);
+        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, S.delta[1], S.rdelta[1], dfr);
+        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, S.delta[2], S.rdelta[2], dfr);
         defer = defer || dfr;
         tnx = ax.tnext; tny = ay.tnext; tnz = az.tnext;
         dtx = ax.dt; dty = ay.dt; dtz = az.dt;
