@@ -1199,6 +1199,7 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     if (tri && !g->prims->prep_sane) o->fast_ok = 0;
     // the walk's wave-uniform quotients, once, in the arithmetic the kernel would use: fp32, correctly rounded
     o->walk_ok = 1;
+    o->nslots = g->cell_offsets->off_last;   // validated by check_grid above
     for (int k = 0; k < 3; ++k) {
         const float span = g->bounds[4 + k] - g->bounds[k];
         const float delta = span / (float)g->n_slabs;

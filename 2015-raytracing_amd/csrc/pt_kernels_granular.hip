@@ -222,7 +222,7 @@ PT_DEV GridArgs mk_set(const float4* prims, const uint32_t* off, const Box8& b, 
     for (int i = 0; i < 8; ++i) S.bound[i] = b.v[i];
     S.n = n; S.mesh_matid = 0; S.kind = 0; S.fast_ok = 0; S.lds_off = kNoLds; S.exit_is_far_face = exit_far;
     for (int i = 0; i < 3; ++i) { S.delta[i] = 0.0f; S.rdelta[i] = 0.0f; }   // the optimistic kernel's (these kernels divide for themselves)
-    S.walk_ok = 0;
+    S.walk_ok = 0; S.nslots = 0;
     return S;
 }
 template <int KIND>

@@ -49,6 +49,7 @@ struct GridArgs {            // one cell-sorted primitive set, device pointers
     uint32_t lds_off;        // n > 1, fused pass: dword index of this set's cell-offset table inside the block's LDS copy, or
                              // kNoLds when the tables of the scene do not fit (launch_fused assigns it)
     float delta[3], rdelta[3]; // n > 1, optimistic kernel: the cell width per axis (hi - lo) / n and its reciprocal, both correctly rounded --
+    uint32_t nslots;         // off[n^3], the number of (cell, primitive) slots, when the host knows it (0: the walk reads it from the table)
     uint32_t walk_ok;        // what every lane would compute for itself from wave-uniform inputs (pt_trace.hpp axis_setup_t).  walk_ok: the
                              // widths and spans sit inside the windows in which the kernel's 3-operation divisions are exact; a lane that
                              // walks a set without it hands its sample to the exact kernel

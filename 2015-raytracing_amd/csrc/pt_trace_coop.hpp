@@ -115,9 +115,12 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
     }
     keys[lane] = kNone;
     // one past the last slot of the set: a (ray, primitive) pair is only ever formed below it (a table that lies cannot send a load astray)
-    uint32_t nslots, unused_;
-    cell_range<LDS_TABLES>(S, off, zs * S.n - 1u, unused_, nslots);
-    nslots = __builtin_amdgcn_readfirstlane(nslots);
+    uint32_t nslots = S.nslots;
+    if (nslots == 0u) {
+        uint32_t unused_;
+        cell_range<LDS_TABLES>(S, off, zs * S.n - 1u, unused_, nslots);
+        nslots = __builtin_amdgcn_readfirstlane(nslots);
+    }
 
     for (;;) {
         // ---- phase A: through empty cells (code.cl:1028-1066's step, unchanged)
