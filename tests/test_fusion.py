@@ -89,10 +89,18 @@ def _unfused(ctx, sc, seeds, drive):
     from raytracing_amd.pyhost import render
     ctx.set_fusion(0)
     g = render.GranularRenderer(ctx, sc, seeds=seeds)
+    _define_struct_buffers(ctx, g)
     drive(g)
     out = {k: g.read(k).copy() for k in ("acu", "seeds", "pixel", "rays", "pois", "shadow")}
     g.release()
     return out
+
+
+def _define_struct_buffers(ctx, g):
+    """The kernels leave parts of a Ray / Poi unwritten (o and d of a dead ray, p and normal of a vertex never hit: SURVEY 8a), i.e. whatever
+    the allocation held.  Zero them so that two runs can be compared byte for byte."""
+    for name in ("rays", "pois", "shadow"):
+        ctx.zero(g.b[name])
 
 
 def _same(got, want, keys):
@@ -168,6 +176,21 @@ def light_block_differs_in_a_bounce(g):
     g.ctx.finish()
 
 
+@stream
+def bounce_rays_into_another_buffer(g):
+    """bouncePaths writes its rays into a second buffer the trace kernels never read: legal, pointless, and not executeRender's
+    data flow -- every bounce segment re-traces the primary rays"""
+    alt = g.ctx.buffer(g.total_rays * g.ray_size)
+    g.ctx.zero(alt)
+    g.k["bouncePaths"].set_arg(1, alt)
+    try:
+        g.execute_render(bounces=2)
+    finally:
+        g.k["bouncePaths"].set_arg(1, g.b["rays"])
+        g.ctx.finish()
+        alt.release()
+
+
 @pytest.mark.parametrize("which", sorted(STREAMS))
 def test_streams_that_are_not_a_pass_run_unchanged(ctx, pkg, which):
     """Level 2 on a stream the matcher must refuse == level 0 on the same stream, for EVERY buffer (Ray / Poi / shadow included: nothing
@@ -177,6 +200,7 @@ def test_streams_that_are_not_a_pass_run_unchanged(ctx, pkg, which):
     want = _unfused(ctx, sc, fx["seeds_in"], STREAMS[which])
     ctx.set_fusion(2)
     g = render.GranularRenderer(ctx, sc, seeds=fx["seeds_in"])
+    _define_struct_buffers(ctx, g)
     STREAMS[which](g)
     got = {k: g.read(k).copy() for k in want}
     assert ctx.fused_passes() == 0
