@@ -62,7 +62,12 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
 #ifndef PT_PARK_PN
 #define PT_PARK_PN 0   // A/B: parking p and n as well is slower (199.9 vs 196.2 ms): the reloads sit on the critical path
 #endif
-#define PT_PARK_WORDS (PT_PARK_PN ? 13 : 7)
+#ifndef PT_PARK_PN_GRIDS
+#define PT_PARK_PN_GRIDS 1   // the same for the grid kernels only: their walks hold far more state (38 -> 22 spilled VGPRs; cornell_teapot3 859 -> 880
+                             // Msamples/s, own_gems 2399 -> 2541)
+#endif
+#define PT_PARK_PN_FOR(GRIDS) (PT_PARK_PN || (PT_PARK_PN_GRIDS && (GRIDS) != 0))
+#define PT_PARK_WORDS(GRIDS) (PT_PARK_PN_FOR(GRIDS) ? 13 : 7)
 struct Park {
 #if PT_PARK_LDS
     float* base;   // &park[0][threadIdx.x]
@@ -118,8 +123,8 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
             poi.n = norm3(fma3(ch.gamma, ld3(nn[2]), fma3(w, ld3(nn[0]), scl3(ch.beta, ld3(nn[1])))));
             poi.matId = (int32_t)(S.matid ? ((const uint32_t*)S.matid)[ch.idx] : S.mesh_matid);
         }
-#if PT_PARK_LDS && PT_PARK_PN
-        park.put_pn(poi);
+#if PT_PARK_LDS
+        if (PT_PARK_PN_FOR(GRIDS)) park.put_pn(poi);
 #endif
     }
 }
@@ -138,8 +143,8 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
         sh.mint = PT_INF;
         sh.maxt = PT_INF;
         if (path) {
-#if PT_PARK_LDS && PT_PARK_PN
-            park.get_pn(poi);
+#if PT_PARK_LDS
+            if (PT_PARK_PN_FOR(GRIDS)) park.get_pn(poi);
 #endif
             sh = shadow_ray(poi, ld3(L.shadow), ld3(L.shadow + 3), ld3(L.shadow + 6), L.shadow[9], seed);
             if (FAST) defer = defer || !ray_guard(sh);
@@ -176,9 +181,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
         if (!path || (uint32_t)poi.matId >= A.nmat) continue;  // out-of-range id: shade nothing (see k_sceneRender)
         float4 c4 = material[poi.matId];
 #if PT_PARK_LDS
-#if PT_PARK_PN
-        park.get_pn(poi);
-#endif
+        if (PT_PARK_PN_FOR(GRIDS)) park.get_pn(poi);
         poi.atte = mk3(park.get(4), park.get(5), park.get(6));
         f3 c = shade_vertex(poi, sh, mk3(c4.x, c4.y, c4.z), ld3(L.scene), ld3(L.scene + 3), ld3(L.scene + 6), L.scene[9]);
         park.put(4, poi.atte.x); park.put(5, poi.atte.y); park.put(6, poi.atte.z);
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     if (!A.fresh) acc = ((const float4*)A.acu)[lid];
     Park park;
 #if PT_PARK_LDS
-    __shared__ float park_mem[PT_PARK_WORDS][256];
+    __shared__ float park_mem[PT_PARK_WORDS(GRIDS)][256];
     park.base = &park_mem[0][threadIdx.x];
     park.put(0, acc.x); park.put(1, acc.y); park.put(2, acc.z); park.put(3, acc.w);
     park.put(4, 1.0f); park.put(5, 1.0f); park.put(6, 1.0f);
@@ -311,8 +314,8 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     for (uint32_t seg = 0; seg <= A.bounces; ++seg) {
         if (seg > 0) {
             if (poi.matId >= 0) {
-#if PT_PARK_LDS && PT_PARK_PN
-                park.get_pn(poi);
+#if PT_PARK_LDS
+                if (PT_PARK_PN_FOR(GRIDS)) park.get_pn(poi);
 #endif
                 ray = bounce_ray(poi, seed);
             } else {
