@@ -598,7 +598,16 @@ int mirt_ctx_set_stream(mirt_ctx* ctx, void* hip_stream) try {
 int mirt_finish(mirt_ctx* ctx) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_finish: unknown context");
     NOT_WHILE_CAPTURING(ctx, "mirt_finish");
-    if (ctx->fusion >= 2 && !ctx->pending.empty()) return MIRT_OK;   // inside a held pass (the reference calls finish() after every sceneRender, A10 code.js:1406): nothing is observable until a read, which flushes
+    // inside a held pass (the reference calls finish() after every sceneRender, A10 code.js:1406) nothing is observable until a read, which
+    // flushes -- unless the pass works on memory the caller can reach behind the ABI (mirt_buf_wrap): then finish() means finish
+    if (ctx->fusion >= 2 && !ctx->pending.empty()) {
+        bool wrapped = false;
+        for (const auto& p : ctx->pending)
+            for (size_t j = 0; j < p.args.size(); ++j)
+                if (p.spec->args[j] == A_BUF && live_has(p.args[j].buf) && !p.args[j].buf->owned) wrapped = true;
+        if (!wrapped) return MIRT_OK;
+        FLUSH_PENDING(ctx);
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return MIRT_OK;
@@ -646,7 +655,11 @@ int mirt_buf_invalidate(mirt_buf* buf) try {
 } MIRT_CATCH("mirt_buf_invalidate", return MIRT_E_DEVICE)
 
 size_t mirt_buf_size(const mirt_buf* buf) try { return live_has(buf) ? buf->bytes : 0; } MIRT_CATCH("mirt_buf_size", return 0)
-void* mirt_buf_device_ptr(const mirt_buf* buf) try { return live_has(buf) ? buf->ptr : nullptr; } MIRT_CATCH("mirt_buf_device_ptr", return nullptr)
+void* mirt_buf_device_ptr(const mirt_buf* buf) try {
+    if (!live_has(buf)) return nullptr;
+    if (live_has(buf->ctx)) (void)flush_pending(buf->ctx);   // the caller is about to look at the memory itself
+    return buf->ptr;
+} MIRT_CATCH("mirt_buf_device_ptr", return nullptr)
 
 int mirt_buf_write(mirt_buf* buf, size_t offset, size_t nbytes, const void* host, int blocking) try {
     (void)blocking;

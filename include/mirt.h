@@ -202,7 +202,9 @@ MIRT_API int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on);
  *     stream both ways); the Ray, Poi and shadow-Ray buffers are NOT written by a fused pass -- they keep their previous contents.
  *     The reference host never reads them (it cannot: it does not know their layout beyond sizeof).
  *   - mirt_finish inside a held pass returns without draining anything (the reference calls finish() after every sceneRender,
- *     code.js:1406); the work runs at the copyToPixel.  Host-side timing of individual kernels is therefore meaningless.
+ *     code.js:1406); the work runs at the copyToPixel.  Host-side timing of individual kernels is therefore meaningless.  A held pass
+ *     that involves a wrapped buffer (mirt_buf_wrap: memory the caller can reach behind the ABI) IS drained by mirt_finish, and
+ *     mirt_buf_device_ptr drains whatever is held.
  *   - errors of a held enqueue (a buffer too small, a grid failing validation) are reported by the call that flushes it, and the
  *     held enqueues after the failing one are dropped (at level 0 the host would have stopped at that enqueue's exception).
  * Level 0 (default): every enqueue launches its kernel.  The environment variable MIRT_FUSION=2 sets the level of every new
