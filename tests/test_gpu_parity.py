@@ -370,6 +370,65 @@ def test_loose_spheres_and_triangles_in_grids(ctx, pkg, name, n):
     gr.release()
 
 
+def _mesh_with_bounds(m, f):
+    b = list(m["bounds"])
+    f(b)
+    return dict(m, bounds=b)
+
+
+def _flatten_z(b):
+    b[6] = b[2]                      # zero-width box on z: the slab width is 0, every quotient by it is inf or NaN
+
+
+def _invert_x(b):
+    b[0], b[4] = b[4], b[0]          # min > max: a miss for every ray (code.cl:301-333)
+
+
+def _inflate(b):
+    for k in range(3):
+        c, h = 0.5 * (b[k] + b[4 + k]), 0.5 * (b[4 + k] - b[k])
+        b[k], b[4 + k] = float(np.float32(c - 7.0 * h)), float(np.float32(c + 7.0 * h))   # the lists no longer match the cells: windows reject most hits
+
+
+GRID_DEGENERATE = {
+    "nan_rays_rpp9": lambda sc: _variant(sc, width=40, height=24, rays_per_pixel=9),                       # the centre sample of a 3 x 3 lens grid is NaN
+    "teapot_box_zero_width": lambda sc: _variant(sc, meshes=[_mesh_with_bounds(sc.d["meshes"][0], _flatten_z)] + list(sc.d["meshes"][1:])),
+    "room_box_zero_width": lambda sc: _variant(sc, meshes=[sc.d["meshes"][0], _mesh_with_bounds(sc.d["meshes"][1], _flatten_z)]),
+    "teapot_box_inverted": lambda sc: _variant(sc, meshes=[_mesh_with_bounds(sc.d["meshes"][0], _invert_x)] + list(sc.d["meshes"][1:])),
+    "room_box_inflated": lambda sc: _variant(sc, meshes=[sc.d["meshes"][0], _mesh_with_bounds(sc.d["meshes"][1], _inflate)]),
+    "one_wave_row_65x1": lambda sc: _variant(sc, width=65, height=1, rays_per_pixel=4),                    # 260 rays: one full block and four lanes of the next
+}
+
+
+@pytest.mark.parametrize("case", sorted(GRID_DEGENERATE))
+def test_degenerate_grids_match_oracle(ctx, pkg, case):
+    """Grid sets whose declared box is the caller's word and a bad one (zero width: the slab width divides by zero; inverted; far larger than
+    the geometry, so that cell lists and cells no longer agree), NaN rays through the grids, and a tile that leaves most of a block without
+    samples.  The shared-test walk, the exact kernel and the kernel-by-kernel path against the CPU oracle."""
+    from raytracing_amd.pyhost import render
+    fx, sc0 = load_fixture("cornell_teapot3_32x24_r4")
+    sc = GRID_DEGENERATE[case](sc0)
+    seeds = A.make_seeds(sc.total_rays, seed_base=11)
+    orc = A.load_oracle()
+    st = A.PassState(sc, seeds)
+    A.run_pass(orc, sc, st)
+    for exact_only in (False, True):
+        ctx.set_exact_only(exact_only)
+        fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+        fr.execute_render()
+        assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(st.acu)), f"fused, exact_only={exact_only}"
+        assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
+        assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), st.pixel)
+        fr.release()
+    ctx.set_exact_only(False)
+    gr = render.GranularRenderer(ctx, sc, seeds=seeds)
+    gr.execute_render()
+    got = snapshot(gr)
+    assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds), "granular"
+    assert np.array_equal(got["pois"]["matId"], st.pois["matId"])
+    gr.release()
+
+
 @pytest.mark.parametrize("name", ["cornell_16x12_r9", "cornell_teapot3_32x24_r4"])
 def test_first_pass_initialises_the_accumulator(ctx, pkg, name):
     """mirt_render_first_pass = initAcu folded into the pass: over an accumulator full of junk it gives what zeroing + a normal pass
