@@ -158,7 +158,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
                 if (live) {
                     const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(sh, set_box(S));
                     if (bh.v) {
-                        ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, true, TRI_A10, FAST>(sh, bh, S) : trace_cell1<TRIANGLES, true, TRI_A10, FAST>(sh, bh, S);
+                        ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, true, TRI_A10, FAST, true>(sh, bh, S) : trace_cell1<TRIANGLES, true, TRI_A10, FAST, true>(sh, bh, S);
                         walked = true;
                     }
                 }

@@ -221,7 +221,10 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
 
 // One primitive set.  KIND / ANY as in pt_device.hpp.
 // trace_cell1: n == 1, a single cell, every lane walks the same list -> wave-uniform loop, scalar loads.
-template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false>
+// FLAG_ONLY (with ANY): the caller only asks whether the ray is blocked (the fused pass: sceneRender compares mint with maxt and nothing
+// else of the shadow ray survives the kernel).  The loop then keeps one flag instead of the hit record: idx != UINT32_MAX says blocked, t
+// is not delivered.
+template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false, bool FLAG_ONLY = false>
 PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
@@ -264,6 +267,11 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         } else {
             hit = tri_test<RULE, FAST, PT_UNIFORM_CULL != 0>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, gm);
         }
+        if (ANY && FLAG_ONLY) {
+            done = done | ((int)hit & (int)(ti < ray.maxt));   // the first hit ends the reference's loop: ch.t is still maxt when it is compared
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+            continue;
+        }
         const bool better = (int)!done & (int)hit & (int)(ti < ch.t);
         ch.t = better ? ti : ch.t;          // selects, not a branch: some lane of an incoherent wave almost always hits
         ch.idx = better ? i : ch.idx;
@@ -274,6 +282,7 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
             if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every lane of the wave is blocked
         }
     }
+    if (ANY && FLAG_ONLY && done) ch.idx = 0u;
     return ch;
 }
 
