@@ -25,6 +25,9 @@
 // every value that reaches a ray-dependent operation has the bits it has in the reference.
 #include "pt_trace_coop.hpp"
 
+#ifndef PT_SKIP_DARK_SHADOWS
+#define PT_SKIP_DARK_SHADOWS 1   // grid kernels: a shadow ray whose vertex the light cannot light is not traced (direct_all)
+#endif
 #ifndef PT_AABB_UNSIGNED_ZERO
 #define PT_AABB_UNSIGNED_ZERO 1   // single-cell sets only (their tmin / tmax / exits are compare-only): see slab1_fast
 #endif
@@ -137,6 +140,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
     for (uint32_t l = 0; l < A.n_lights; ++l) {
         const LightArgs& L = A.lights[l];
         const bool path = poi.matId >= 0;  // initShadowTrace: a dead path draws nothing (code.cl:645-650)
+        bool dark = false;
         Ray sh;
         sh.o = mk3(0.0f, 0.0f, 0.0f);
         sh.d = mk3(0.0f, 0.0f, 0.0f);
@@ -147,11 +151,26 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             if (PT_PARK_PN_FOR(GRIDS)) park.get_pn(poi);
 #endif
             sh = shadow_ray(poi, ld3(L.shadow), ld3(L.shadow + 3), ld3(L.shadow + 6), L.shadow[9], seed);
+#if PT_SKIP_DARK_SHADOWS
+            if (GRIDS) {
+                // A vertex the light cannot light -- cosx * cosy == 0 in sceneRender's term (code.cl:1339-1349): the surface or the
+                // emitter faces away -- adds area * (0 / r^2) * E = 0 whether or not the shadow ray is blocked (a blocked one adds the
+                // literal 0; the accumulator, a sum of non-negative terms from +0, cannot tell one zero from another).  Nothing else of the
+                // shadow ray survives the kernel, so it is not traced.  Needs r^2 > 0 (else 0 / 0) and finite area and irradiance.
+                const float cosx = cl_clamp(dot3(sh.d, poi.n), 0.0f, 1.0f);
+                const float cosy = cl_clamp(dot3(neg3(sh.d), ld3(L.scene + 3)), 0.0f, 1.0f);
+                const float r = len3(sub3(poi.p, ld3(L.scene)));
+                const float fin = L.scene[9] * 0.0f + L.scene[6] * 0.0f + L.scene[7] * 0.0f + L.scene[8] * 0.0f;   // 0 iff all four are finite
+                dark = (cosx * cosy == 0.0f) & (r * r > 0.0f) & (fin == 0.0f);
+            }
+            if (FAST && !dark) defer = defer || !ray_guard(sh);
+#else
             if (FAST) defer = defer || !ray_guard(sh);
+#endif
         }
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
-            const bool live = path && !(sh.mint == sh.maxt);
+            const bool live = path && !dark && !(sh.mint == sh.maxt);
             Hit ch;
             bool walked = false;
             if (!GRIDS || S.n == 1u) {
