@@ -44,13 +44,13 @@ BYTES_PER_SAMPLE_FUSED = 24.0       # seed 4 in + 4 out, accumulator 16 out (a f
 BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0
 PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA-counted)
 PEAK_HBM_GBS = 8000.0
-# VALU wave-instructions per sample-lane (SQ_INSTS_VALU / SQ_WAVES, profiles/r2e_final) and the issue rate one SIMD sustains on
+# VALU wave-instructions per sample-lane (SQ_INSTS_VALU / SQ_WAVES, profiles/r2f_final) and the issue rate one SIMD sustains on
 # plain fp32 VOP2 streams at 8 waves (profiles/micro/valu_rate.hip: 2.4 nominal cycles per wave-instruction; the 2-cycle figure is the spec)
-VALU_INSTR_PER_SAMPLE = {8: 19784.0}
+VALU_INSTR_PER_SAMPLE = {8: 19397.0}
 SIMDS, NOMINAL_HZ, MEASURED_ISSUE_CYCLES = 1024, 2.4e9, 2.4
-# HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r2e_final: FETCH_SIZE x 2 + WRITE_SIZE,
+# HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r2f_final: FETCH_SIZE x 2 + WRITE_SIZE,
 # KiB -> bytes; gfx950 halves FETCH_SIZE on wide coalesced reads, MI355X_MICROARCH.md).  Valid for the default workload only.
-TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 2.12e9, "write_bytes": 10.62e9, "source": "profiles/r2e_final/pmc_summary.json"}
+TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 2.12e9, "write_bytes": 10.62e9, "source": "profiles/r2f_final/pmc_summary.json"}
 
 
 def cpu_baseline(packed_json, log, bounces, rpp=256):
@@ -256,7 +256,7 @@ def main():
             "achieved_Ginstr_s": round(VALU_INSTR_PER_SAMPLE[args.bounces] * local_samples / 64.0 / (fused_ms * 1e-3) / 1e9, 1),
             "attainable_Ginstr_s": round(SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES / 1e9, 1), "spec_Ginstr_s": round(SIMDS * NOMINAL_HZ / 2.0 / 1e9, 1),
             "frac_of_attainable": round(VALU_INSTR_PER_SAMPLE[args.bounces] * local_samples / 64.0 / (fused_ms * 1e-3) / (SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES), 4),
-            "source": "profiles/r2e_final/pmc_summary.json, profiles/micro/README.md"},
+            "source": "profiles/r2f_final/pmc_summary.json, profiles/micro/README.md"},
         "roofline_hbm": {"kernel": kernel_name, "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
                          "traffic_note": ("algorithmic 12.7 GB/launch (seeds in + out, accumulator out); measured 2.12 + 10.62 GB (FETCH_SIZE x2 + WRITE_SIZE, "
