@@ -354,7 +354,7 @@ int caught(const char* fn, const char* what) noexcept {
 
 extern "C" {
 
-const char* mirt_version(void) try { return "mirt 0.1 (gfx950)"; } MIRT_CATCH("mirt_version", return "")
+const char* mirt_version(void) try { return "mirt 0.2 (gfx950)"; } MIRT_CATCH("mirt_version", return "")
 
 int mirt_device_count(void) try {
     int n = 0;
