@@ -7,8 +7,8 @@
 // Here the walk alternates two wave-wide phases:
 //   A  every live lane steps its own DDA through EMPTY cells until it stands in a cell that holds primitives (or has left the grid);
 //   B  the (ray, primitive) pairs of ALL those cells -- lane L contributes end_L - i_L of them -- are laid out back to back
-//      (a wave prefix sum) and tested 64 at a time by whichever lanes are free, each tester fetching "its" ray and cell window from the
-//      owner's record in LDS.  Hits go back to the owner through one LDS atomic: a 64-bit minimum over (t, primitive index).
+//      (a wave prefix sum) and tested 64 at a time by whichever lanes are free, each tester fetching "its" ray from the owner's
+//      record in LDS and the owner's maxt / cell window by ds_bpermute.  Hits go back to the owner through one LDS atomic: a 64-bit minimum over (t, primitive index).
 // A lane's ray meets exactly the cells, and in each cell exactly the primitives with exactly the [cmin, cmax] windows, of the
 // reference's nested loops (A10 code.cl:937-1070, 1195-1321); only WHO evaluates a test and in which order changes.  Order does not
 // matter: inside a cell the reference keeps the hit with the smallest t, the first one among equals (strict <, code.cl:1017-1026) --
@@ -26,15 +26,9 @@ namespace pt {
 
 // One wave's exchange area in the block's dynamic LDS: CW_ROWS rows of 64 words, [row][lane]; 3 KB per wave, 12 KB per block, at
 // the start of the dynamic segment (the staged cell-offset tables follow: launch_fused).
-#ifndef PT_COOP_BPERM
-#define PT_COOP_BPERM 1   // the owner's maxt / cell window / pair base reach a tester through ds_bpermute from the owner's registers instead of four more
-                          // LDS rows (cornell_teapot3 853 -> 859 Msamples/s, and 4 KB of LDS per block back)
-#endif
-#if PT_COOP_BPERM
-enum { CW_OX = 0, CW_OY, CW_OZ, CW_DX, CW_DY, CW_DZ, CW_OWN, CW_T, CW_BETA, CW_GAMMA, CW_KEY /* two rows: 64 x u64 */, CW_ROWS = 12, CW_MAXT = -1, CW_CMIN = -1, CW_CMAX = -1, CW_IBX = -1 };
-#else
-enum { CW_OX = 0, CW_OY, CW_OZ, CW_DX, CW_DY, CW_DZ, CW_MAXT, CW_CMIN, CW_CMAX, CW_IBX, CW_OWN, CW_T, CW_BETA, CW_GAMMA, CW_KEY /* two rows: 64 x u64 */, CW_ROWS = 16 };
-#endif
+// The owner's maxt, cell window and pair base are NOT rows: they reach a tester through ds_bpermute from the owner's registers (four
+// rows = 4 KB of LDS per block less, and cornell_teapot3 853 -> 859 Msamples/s).
+enum { CW_OX = 0, CW_OY, CW_OZ, CW_DX, CW_DY, CW_DZ, CW_OWN, CW_T, CW_BETA, CW_GAMMA, CW_KEY /* two rows: 64 x u64 */, CW_ROWS = 12 };
 constexpr uint32_t kCoopWordsPerBlock = 4u * CW_ROWS * 64u;
 
 template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
@@ -119,9 +113,6 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
         cell_range<LDS_TABLES>(S, off, __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx, i, end);
         CW_MINE(CW_OX) = __float_as_uint(ray.o.x); CW_MINE(CW_OY) = __float_as_uint(ray.o.y); CW_MINE(CW_OZ) = __float_as_uint(ray.o.z);
         CW_MINE(CW_DX) = __float_as_uint(ray.d.x); CW_MINE(CW_DY) = __float_as_uint(ray.d.y); CW_MINE(CW_DZ) = __float_as_uint(ray.d.z);
-#if !PT_COOP_BPERM
-        CW_MINE(CW_MAXT) = __float_as_uint(ray.maxt);
-#endif
     }
     keys[lane] = kNone;
     // one past the last slot of the set: a (ray, primitive) pair is only ever formed below it (a table that lies cannot send a load astray)
@@ -162,13 +153,6 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
         const uint32_t cnt = alive ? end - i : 0u;
         const uint32_t incl = wave_scan_add(cnt), excl = incl - cnt;
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-#if !PT_COOP_BPERM
-        if (alive) {
-            CW_MINE(CW_CMIN) = __float_as_uint(cmin);
-            CW_MINE(CW_CMAX) = __float_as_uint(cmax);
-            CW_MINE(CW_IBX) = i - excl;   // pair p of the wave is primitive (i - excl) + p of this lane's set
-        }
-#endif
         for (uint32_t base = 0u; base < total; base += 64u) {
             // who owns pair base + lane: owners mark the first pair of theirs inside this window, a prefix maximum spreads the mark
             CW_MINE(CW_OWN) = 0u;
@@ -176,28 +160,18 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
             wave_fence();
             const uint32_t mark = wave_scan_max(CW_MINE(CW_OWN));
             const uint32_t p = base + lane;
-#if PT_COOP_BPERM
-            // every lane asks (a lane without a pair asks lane 0 and drops the answer): ds_bpermute reads the owners' registers
+            // pair p of the wave is primitive (i - excl) + p of its owner's set.  Every lane asks (a lane without a pair asks lane 0 and drops the answer): ds_bpermute reads the owners' registers
             const int oaddr = (int)((mark != 0u ? mark - 1u : 0u) << 2);
             const float omax = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(ray.maxt)));
             const float ocmin = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(cmin)));
             const float ocmax = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(cmax)));
             const uint32_t oibx = (uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)(i - excl));
-#endif
             if (p < total && mark != 0u) {
                 const uint32_t o = mark - 1u;
-#if PT_COOP_BPERM
                 const uint32_t prim = oibx + p;
-#else
-                const uint32_t prim = CW_OF(CW_IBX, o) + p;
-#endif
                 if (prim < nslots) {
                     const f3 ro = mk3(__uint_as_float(CW_OF(CW_OX, o)), __uint_as_float(CW_OF(CW_OY, o)), __uint_as_float(CW_OF(CW_OZ, o)));
                     const f3 rd = mk3(__uint_as_float(CW_OF(CW_DX, o)), __uint_as_float(CW_OF(CW_DY, o)), __uint_as_float(CW_OF(CW_DZ, o)));
-#if !PT_COOP_BPERM
-                    const float omax = __uint_as_float(CW_OF(CW_MAXT, o));
-                    const float ocmin = __uint_as_float(CW_OF(CW_CMIN, o)), ocmax = __uint_as_float(CW_OF(CW_CMAX, o));
-#endif
                     const float4* __restrict__ q = prims + 3u * (size_t)prim;
                     float tt, bb, gg;
                     if (tri_test<TRI_A10, FAST>(ro, rd, ocmin, ocmax, q[0], q[1], q[2], tt, bb, gg) && tt < omax) {
