@@ -127,6 +127,7 @@ struct mirt_buf {
     uint64_t off_version = 0;
     uint32_t off_n = 0;
     uint32_t off_last = 0;
+    uint32_t prep_count = 0;   // records in `prep` (the group spheres sit at record index prep_count)
     // prepared-triangle copy of a position buffer (fused path), rebuilt when the contents change
     void* prep = nullptr;
     size_t prep_bytes = 0;
@@ -283,8 +284,10 @@ uint32_t exit_is_far_face(const float* b8, uint32_t n) {
 
 // (re)builds the prepared-triangle copy of a position buffer when its contents changed
 int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
-    const size_t bytes = (size_t)count * 48;
-    if (pb->owned && pb->prep_version == pb->version && pb->prep_bytes >= bytes && (pb->prep || !bytes)) { pin(ctx, pb, true); return MIRT_OK; }
+    // [count records of 48 B][one bounding sphere (float4) per group of records]: the spheres sit right behind the records, so a prepared copy is
+    // good for exactly the count it was made for
+    const size_t bytes = pt::prepared_bytes(count);
+    if (pb->owned && pb->prep_version == pb->version && pb->prep_count == count && pb->prep_bytes >= bytes && (pb->prep || !bytes)) { pin(ctx, pb, true); return MIRT_OK; }
     NOT_WHILE_CAPTURING(ctx, "preparing a new triangle buffer");
     if (pb->prep && pb->prep_bytes < bytes) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(pb->prep)); pb->prep = nullptr; pb->prep_bytes = 0; pb->prep_gen++; }
     if (bytes && !pb->prep) { HIPCHK(ctx, hipMalloc(&pb->prep, bytes)); pb->prep_bytes = bytes; pb->prep_gen++; }
@@ -297,6 +300,7 @@ int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     pb->prep_sane = insane == 0;
     pb->prep_version = pb->version;
+    pb->prep_count = count;
     return MIRT_OK;
 }
 

@@ -112,7 +112,15 @@ __global__ void __launch_bounds__(256) k_a04_meshTrace(uchar4* pixels, F16 cam16
     // early-outs a wave ballot asks whether ANY lane is still in; if none is, the rest of the test is skipped for the wave.  Lanes
     // that are still in compute exactly the values the straight-line test computes, so nothing changes but the work.
     const float4* __restrict__ p = prep;
+    const float4* __restrict__ groups = prep + 3u * (size_t)t_size;   // one bounding sphere per kTriGroup records (k_prepTriangles)
+    const float dd = ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z;
     for (uint32_t i = 0; i < t_size; ++i, p += 3) {
+        // a whole group none of the wave's 64 rays can reach (pt_trace.hpp group_missed) is skipped
+        if ((i % kTriGroup) == 0u && i + kTriGroup <= t_size && __builtin_amdgcn_ballot_w64(!group_missed(ray, dd, groups[i / kTriGroup])) == 0ull) {
+            i += kTriGroup - 1u;
+            p += 3u * (kTriGroup - 1u);
+            continue;
+        }
         const float4 A = p[0], B = p[1], C = p[2];
         const f3 p0 = mk3(A.x, A.y, A.z), e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z), n = mk3(A.w, B.w, C.w);
         const float div = dot3(n, ray.d);

@@ -53,6 +53,28 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
     auto big = [](float v) { return !(__builtin_fabsf(v) <= 2097152.0f); };
     if (bad(n.x) || bad(n.y) || bad(n.z) || big(p0.x) || big(p0.y) || big(p0.z) || big(e1.x) || big(e1.y) || big(e1.z) || big(e2.x) || big(e2.y) || big(e2.z))
         atomicOr(insane, 1u);
+    // One bounding sphere per group of kTriGroup consecutive records, behind the records: {centre, R'^2} with R' the radius inflated by
+    // 1 % plus what the centre's own rounding can move it (pt_trace.hpp group_missed).  The frame kernels of Assign04 / 07 skip a group
+    // whose sphere the ray's line misses.
+    if ((i % kTriGroup) == 0u) {
+        const uint32_t last = i + kTriGroup < count ? i + kTriGroup : count;
+        f3 lo = p0, hi = p0;
+        for (uint32_t k = 3u * i; k < 3u * last; ++k) {
+            const f3 v = ld3(pos[k]);
+            lo = mk3(__builtin_fminf(lo.x, v.x), __builtin_fminf(lo.y, v.y), __builtin_fminf(lo.z, v.z));
+            hi = mk3(__builtin_fmaxf(hi.x, v.x), __builtin_fmaxf(hi.y, v.y), __builtin_fmaxf(hi.z, v.z));
+        }
+        const f3 c = mk3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+        float r2 = 0.0f;
+        for (uint32_t k = 3u * i; k < 3u * last; ++k) {
+            const f3 v = sub3(ld3(pos[k]), c);
+            r2 = __builtin_fmaxf(r2, v.x * v.x + v.y * v.y + v.z * v.z);
+        }
+        const float cm = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(c.x), __builtin_fabsf(c.y)), __builtin_fabsf(c.z));
+        const float r = __builtin_sqrtf(r2) * 1.01f + 1e-5f * cm + 1e-30f;
+        // a NaN anywhere makes r2 NaN or the compare below false: such a group is never skipped
+        ((float4*)(out + 3u * (size_t)count))[i / kTriGroup] = make_float4(c.x, c.y, c.z, r * r);
+    }
 }
 
 // Cold per-ray state parked in LDS instead of registers: the accumulator (touched once per shading event) and the
@@ -413,6 +435,7 @@ void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint
     if (words) hipLaunchKernelGGL(k_deferCount, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, count);
 }
 
+size_t prepared_bytes(uint32_t count) { return (size_t)count * 48 + ((size_t)count + kTriGroup - 1) / kTriGroup * 16; }
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word) {
     if (!count) return;
     hipLaunchKernelGGL(k_prepTriangles, dim3((count + 255) / 256), dim3(256), 0, s, (const float4*)pos, (float4*)out, count, insane_word);

@@ -82,8 +82,10 @@ struct FusedArgs {
 void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words);
 bool fused_fast_available();   // compiled with PT_EXACT_FAST_DIV
 void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count);
-// {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip)
+// {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip); `out` holds count records of 48 B and,
+// behind them, ceil(count / 8) float4 {centre, R'^2}: the bounding spheres of groups of 8 consecutive records
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word);
+size_t prepared_bytes(uint32_t count);   // what `out` must hold for `count` triangles
 
 // ---- uniform-grid build on the device (pt_grid_build.hip) -------------------------------------------
 constexpr uint64_t kMaxGridSlots = 0x7FFFFFFFull;   // (cell, primitive) slots one grid may hold: the sort and every consumer index them with 31 bits

@@ -63,6 +63,23 @@ PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const f
     return ok != 0;
 }
 
+// Groups of kTriGroup consecutive prepared triangles carry a bounding sphere {c, R'^2} behind the records (k_prepTriangles).  A ray whose
+// LINE passes the centre at more than R' misses every triangle of the group geometrically, by at least a hundredth of the group's radius:
+// far more than the rounding of the reference's barycentrics (relative 1e-6), so each of the reference's tests on them rejects
+// (A04 / A07 code.cl interTriangle) and skipping the group changes nothing.  |v x d|^2 = |v|^2 |d|^2 - (v.d)^2 is evaluated with its
+// cancellation error (<= 8 eps |v|^2 |d|^2) on the safe side; a NaN anywhere compares false = not missed.
+#ifndef PT_TRI_GROUP
+#define PT_TRI_GROUP 16
+#endif
+constexpr uint32_t kTriGroup = PT_TRI_GROUP;
+PT_DEV bool group_missed(const Ray& ray, float dd, const float4 g) {
+    const f3 v = sub3(mk3(g.x, g.y, g.z), ray.o);
+    const float b = v.x * ray.d.x + v.y * ray.d.y + v.z * ray.d.z;
+    const float c2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float q = __builtin_fmaf(-b, b, c2 * dd);
+    return q > dd * __builtin_fmaf(1e-6f, c2, g.w);
+}
+
 // The same test, STAGED, for loops where every active lane holds a (possibly different) triangle and most lanes are rejected early
 // (the frame kernels of Assign04 / 07: adjacent pixels against small triangles): after each of the reference's early-outs a wave ballot
 // asks whether ANY lane is still in; if none is, the rest is skipped for the whole wave.  Lanes that are still in compute exactly the values
