@@ -1167,7 +1167,7 @@ static int launch_kernel(mirt_ctx* ctx, const KernelSpec& S, std::vector<KArg>& 
             } else {
                 if ((rc = check_grid(ctx, "meshTrace grid", BUF(10), U(9), BUF(4), 48, BUF(5), nullptr))) return rc;
                 if ((rc = ensure_prepared(ctx, BUF(4), BUF(10)->off_last))) return rc;
-                pt::launch_a07_meshTrace(st, BUF(0)->ptr, V(1), BUF(2)->ptr, BUF(4)->prep, BUF(5)->ptr, V(8), U(9), BUF(10)->ptr, g0, g1);
+                pt::launch_a07_meshTrace(st, BUF(0)->ptr, V(1), BUF(2)->ptr, BUF(4)->prep, BUF(5)->ptr, V(8), U(9), BUF(10)->ptr, BUF(10)->off_last, g0, g1);
             }
             break;
         }

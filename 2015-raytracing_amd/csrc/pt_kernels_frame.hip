@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_a04_meshTrace(uchar4* pixels, F16 cam16
 
 // ---- Assign07 meshTrace: 3-D grid DDA, colour = parity of the hit cell x fake shade -------------------
 __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16, RayAoS* rays, const float4* prep, const float4* normals,
-                                                        Box8 bound8, uint32_t n_slabs, const uint32_t* slab_size, uint32_t gx, uint32_t gy) {
+                                                        Box8 bound8, uint32_t n_slabs, const uint32_t* slab_size, uint32_t group_slots, uint32_t gx, uint32_t gy) {
     const Cam cam = mk_cam(cam16);
     uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t row = blockIdx.y * blockDim.y + threadIdx.y;
@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16
     float t = bh.tmin, cmin = t, cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
     uint32_t cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
     uint32_t i = slab_size[cell], end = slab_size[cell + 1];
+    const float dd = ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z;
     for (;;) {
         bool alive = true;
         while (i == end) {
@@ -199,6 +200,17 @@ __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16
             end = slab_size[cell + 1];
         }
         if (!alive) break;
+        // Coarse grids (the page's n_slabs = 2: a thousand slots per cell): when every lane still in has at least a whole group of
+        // kTriGroup slots ahead in its list and none of their rays can reach its own group's bounding sphere (pt_trace.hpp group_missed),
+        // all step over that group together -- per lane the skip is exact on its own, the ballot only keeps the wave in step.
+        if (group_slots != 0u) {
+            const bool whole = ((i % kTriGroup) == 0u) & (end - i >= kTriGroup);
+            if (__builtin_amdgcn_ballot_w64(!whole) == 0ull &&
+                __builtin_amdgcn_ballot_w64(!group_missed(ray, dd, (prep + 3u * (size_t)group_slots)[i / kTriGroup])) == 0ull) {
+                i += kTriGroup;
+                continue;
+            }
+        }
         float ti, b, g;
         const float4* __restrict__ p = prep + 3u * (size_t)i;
         // adjacent pixels walk the same cells in nearly the same order: staged rejection with wave ballots (tri_test_staged)
@@ -298,10 +310,13 @@ void launch_a04_meshTrace(hipStream_t s, void* pixels, const float* cam, void* r
                        (const float4*)normals, (const uint32_t*)mindex, (const float4*)mcolor, ncolors, gx, gy);
 }
 void launch_a07_meshTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* prep, const void* normals, const float* bound,
-                          uint32_t n_slabs, const void* slab_size, uint32_t gx, uint32_t gy) {
+                          uint32_t n_slabs, const void* slab_size, uint32_t n_slots, uint32_t gx, uint32_t gy) {
     if (!gx || !gy) return;
+    // the group spheres behind the n_slots records are consulted only where cells are long on average (coarse grids)
+    const uint64_t cells = (uint64_t)n_slabs * n_slabs * n_slabs;
+    const uint32_t group_slots = (uint64_t)n_slots >= cells * 4u * kTriGroup ? n_slots : 0u;
     hipLaunchKernelGGL(k_a07_meshTrace, grid2(gx, gy), dim3(32, 8), 0, s, (uchar4*)pixels, mk16f(cam), (RayAoS*)rays, (const float4*)prep,
-                       (const float4*)normals, mk8f(bound), n_slabs, (const uint32_t*)slab_size, gx, gy);
+                       (const float4*)normals, mk8f(bound), n_slabs, (const uint32_t*)slab_size, group_slots, gx, gy);
 }
 
 void launch_a07_molTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* atoms, const float* bound, uint32_t n_slabs,

@@ -105,8 +105,9 @@ void launch_a01_raytrace(hipStream_t s, void* pixels, const float* cam, uint32_t
 void launch_frame_initTrace(hipStream_t s, bool clip, void* pixels, const float* cam, void* rays, const float* bound, uint32_t gx, uint32_t gy);
 void launch_a04_meshTrace(hipStream_t s, void* pixels, const float* cam, void* rays, uint32_t t_size, const void* prep, const void* normals,
                           const void* mindex, const void* mcolor, uint32_t ncolors, uint32_t gx, uint32_t gy);
+// prep: the prepared records of the n_slots grid slots followed by one bounding sphere per kTriGroup records (launch_prepTriangles)
 void launch_a07_meshTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* prep, const void* normals, const float* bound,
-                          uint32_t n_slabs, const void* slab_size, uint32_t gx, uint32_t gy);
+                          uint32_t n_slabs, const void* slab_size, uint32_t n_slots, uint32_t gx, uint32_t gy);
 void launch_a07_molTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* atoms, const float* bound, uint32_t n_slabs,
                          const void* slab_size, uint32_t gx, uint32_t gy);
 
