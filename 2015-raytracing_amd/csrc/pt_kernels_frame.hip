@@ -150,6 +150,8 @@ __global__ void __launch_bounds__(256) k_a04_meshTrace(uchar4* pixels, F16 cam16
 }
 
 // ---- Assign07 meshTrace: 3-D grid DDA, colour = parity of the hit cell x fake shade -------------------
+// GROUPS: coarse grids (see the loop); a template parameter so that fine grids run the plain loop, untouched
+template <bool GROUPS>
 __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16, RayAoS* rays, const float4* prep, const float4* normals,
                                                         Box8 bound8, uint32_t n_slabs, const uint32_t* slab_size, uint32_t group_slots, uint32_t gx, uint32_t gy) {
     const Cam cam = mk_cam(cam16);
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16
     float t = bh.tmin, cmin = t, cmax = cl_min(cl_min(ax.tnext, ay.tnext), az.tnext);
     uint32_t cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
     uint32_t i = slab_size[cell], end = slab_size[cell + 1];
-    const float dd = ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z;
+    const float dd = GROUPS ? ray.d.x * ray.d.x + ray.d.y * ray.d.y + ray.d.z * ray.d.z : 0.0f;
     for (;;) {
         bool alive = true;
         while (i == end) {
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(256) k_a07_meshTrace(uchar4* pixels, F16 cam16
         // Coarse grids (the page's n_slabs = 2: a thousand slots per cell): when every lane still in has at least a whole group of
         // kTriGroup slots ahead in its list and none of their rays can reach its own group's bounding sphere (pt_trace.hpp group_missed),
         // all step over that group together -- per lane the skip is exact on its own, the ballot only keeps the wave in step.
-        if (group_slots != 0u) {
+        if (GROUPS) {
             const bool whole = ((i % kTriGroup) == 0u) & (end - i >= kTriGroup);
             if (__builtin_amdgcn_ballot_w64(!whole) == 0ull &&
                 __builtin_amdgcn_ballot_w64(!group_missed(ray, dd, (prep + 3u * (size_t)group_slots)[i / kTriGroup])) == 0ull) {
@@ -315,8 +317,12 @@ void launch_a07_meshTrace(hipStream_t s, void* pixels, const float* cam, void* r
     // the group spheres behind the n_slots records are consulted only where cells are long on average (coarse grids)
     const uint64_t cells = (uint64_t)n_slabs * n_slabs * n_slabs;
     const uint32_t group_slots = (uint64_t)n_slots >= cells * 4u * kTriGroup ? n_slots : 0u;
-    hipLaunchKernelGGL(k_a07_meshTrace, grid2(gx, gy), dim3(32, 8), 0, s, (uchar4*)pixels, mk16f(cam), (RayAoS*)rays, (const float4*)prep,
-                       (const float4*)normals, mk8f(bound), n_slabs, (const uint32_t*)slab_size, group_slots, gx, gy);
+    if (group_slots)
+        hipLaunchKernelGGL(k_a07_meshTrace<true>, grid2(gx, gy), dim3(32, 8), 0, s, (uchar4*)pixels, mk16f(cam), (RayAoS*)rays, (const float4*)prep,
+                           (const float4*)normals, mk8f(bound), n_slabs, (const uint32_t*)slab_size, group_slots, gx, gy);
+    else
+        hipLaunchKernelGGL(k_a07_meshTrace<false>, grid2(gx, gy), dim3(32, 8), 0, s, (uchar4*)pixels, mk16f(cam), (RayAoS*)rays, (const float4*)prep,
+                           (const float4*)normals, mk8f(bound), n_slabs, (const uint32_t*)slab_size, 0u, gx, gy);
 }
 
 void launch_a07_molTrace(hipStream_t s, void* pixels, const float* cam, void* rays, const void* atoms, const float* bound, uint32_t n_slabs,
