@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
         }
         const float cm = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(c.x), __builtin_fabsf(c.y)), __builtin_fabsf(c.z));
         const float r = __builtin_sqrtf(r2) * 1.01f + 1e-5f * cm + 1e-30f;
-        // a NaN anywhere makes r2 NaN or the compare below false: such a group is never skipped
+        // (a NaN coordinate is ignored by min / max: the triangle it belongs to can only produce a NaN t, which the reference's own
+        // interval test rejects -- skipping it changes nothing; an infinite one makes the radius infinite: never skipped)
         ((float4*)(out + 3u * (size_t)count))[i / kTriGroup] = make_float4(c.x, c.y, c.z, r * r);
     }
 }
