@@ -214,3 +214,51 @@ def test_full_size_frames_equal_the_reference_binaries(ctx, pkg, name, size):
         got = np.ascontiguousarray(rays).view(A.RAY_DT)
         assert np.array_equal(bits(got["maxt"]), bits(want_rays["maxt"]))
     assert (px[:, :3].max(axis=1) > 0).mean() > 0.02
+
+
+def _random_mesh_job(base04, base07, seed, n):
+    """A random triangle soup inside the parliament fixture's box (its camera then sees it): Assign04 job, or the Assign07 job at n_slabs = n
+    binned by the restatement of the reference host's splitMeshData.  Sizes from specks to slivers as long as the box; a few degenerate ones."""
+    from test_grid_build import expected_grid
+    rng = np.random.default_rng(seed)
+    b = np.asarray(base04["bounds"], np.float64)
+    lo, hi = b[:3], b[4:7]
+    T = int(rng.choice([5, 120, 900, 2500]))
+    c = lo + rng.uniform(0.05, 0.95, size=(T, 1, 3)) * (hi - lo)
+    scale = (hi - lo) * rng.choice([0.003, 0.02, 0.2, 1.0], size=(T, 1, 1))
+    v = (c + rng.uniform(-0.5, 0.5, size=(T, 3, 3)) * scale).astype(np.float32)
+    v[::97, 2] = v[::97, 1]                                    # degenerate: two equal vertices
+    v = np.clip(v, lo.astype(np.float32), hi.astype(np.float32))
+    nrm = rng.normal(size=(T, 3, 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=2, keepdims=True)).astype(np.float32)
+    ncol = len(base04["mcolor"]) // 4
+    mindex = rng.integers(0, ncol, size=T).astype(np.uint32)
+
+    def pack(order):
+        pos = np.zeros((len(order), 3, 4), np.float32)
+        nor = np.zeros((len(order), 3, 4), np.float32)
+        pos[:, :, :3] = v[order]
+        nor[:, :, :3] = nrm[order]
+        return pos.ravel().tolist(), nor.ravel().tolist()
+    if n == 0:
+        pos, nor = pack(np.arange(T))
+        return dict(base04, t_size=T, pos=pos, normal=nor, mindex=mindex.tolist())
+    off, order = expected_grid(1, v.reshape(T, 9).astype(np.float64), [b[0], b[1], b[2], b[4], b[5], b[6]], n)
+    pos, nor = pack(order)
+    return dict(base07, t_size=T, n_slabs=n, slab_size=off.tolist(), pos=pos, normal=nor, mindex=mindex[order].tolist())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", [(s, n) for s in range(6) for n in (0, 1, 2, 5)])
+def test_random_meshes_frames_match_oracle(ctx, pkg, seed, n):
+    """Random triangle soups through the Assign04 brute-force kernel (n = 0) and the Assign07 grid kernel at 1, 2 and 5 cells per axis: the
+    per-group bounding spheres (pt_trace.hpp group_missed) must never skip a triangle the reference's test accepts -- every pixel and every
+    ray's maxt against the CPU oracle."""
+    from raytracing_amd.pyhost import render
+    _, a04 = fixture("frame_a04_parliament_96x64")
+    _, a07 = fixture("frame_a07_parliament_n16_160x120")
+    d = resized(_random_mesh_job(a04, a07, 100 + seed, n), 320, 200)
+    px, rays = render.render_frame(ctx, render.FramePacked(d))
+    want, wrays = F.run_frame("oracle", F.Frame(d))
+    assert np.array_equal(px, want)
+    assert (px[:, :3].max(axis=1) > 0).mean() > 0.004
