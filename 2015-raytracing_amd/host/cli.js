@@ -2,7 +2,7 @@
 // host/cli.js -- command-line front end of the JavaScript host.
 //   node cli.js pack   <scene.xml> <width> <height> <raysPerPixel>                 -> packed kernel inputs as JSON (stdout)
 //   node cli.js render <scene.xml> <width> <height> <raysPerPixel> <passes> <out.rgba> [--granular [--graph|--fusion]] [--device-grid] [--bounces N] [--seeds file.i32] [--gpus N [--force-rccl]]
-//                                                                                   -> RGBA8 frame (+ <out>.radiance.f32) via the N-API addon
+//                                                                                   -> RGBA8 frame, or a PPM when <out> ends in .ppm (+ <out>.radiance.f32) via the N-API addon
 //   node cli.js pack-frame <1|4|7> <mesh.json|mol.pdb|-> <width> <height> [nSlabs]  -> packed inputs of an Assign01/04/07 frame job (stdout)
 //   node cli.js frame      <1|4|7> <mesh.json|-> <width> <height> <nSlabs|0> <out.rgba>  -> RGBA8 frame of that job
 //   node cli.js ingest <mesh.json> <out-prefix> [--device]                          -> parseMeshJSON's arrays (<out>.pos.f64, .nor.f64, .meta.json) by the host or the device
@@ -11,6 +11,15 @@
 const fs = require("fs");
 const path = require("path");
 const scene = require("./scene.js");
+
+// <out> ending in .ppm: a binary PPM (P6) any viewer opens; anything else: the raw RGBA8 frame the page would have put on its canvas
+function writeFrame(out, px, w, h) {
+  const rgba = Buffer.from(px.buffer, px.byteOffset, px.byteLength);
+  if (!/\.ppm$/i.test(out)) { fs.writeFileSync(out, rgba); return; }
+  const rgb = Buffer.alloc(w * h * 3);
+  for (let i = 0, j = 0; i < w * h * 4; i += 4, j += 3) { rgb[j] = rgba[i]; rgb[j + 1] = rgba[i + 1]; rgb[j + 2] = rgba[i + 2]; }
+  fs.writeFileSync(out, Buffer.concat([Buffer.from(`P6\n${w} ${h}\n255\n`, "ascii"), rgb]));
+}
 
 function usage() {
   process.stderr.write(fs.readFileSync(__filename, "utf8").split("\n").slice(1, 11).join("\n") + "\n");
@@ -35,7 +44,7 @@ if (cmd === "pack") {
   if ((i = rest.indexOf("--seeds")) >= 0) { const b = fs.readFileSync(rest[i + 1]); opt.seeds = new Int32Array(b.buffer, b.byteOffset, b.length / 4); }
   const [file, w, h, rpp, passes, out] = [rest[0], +rest[1], +rest[2], +rest[3], +rest[4], rest[5]];
   const res = renderer.renderFile(file, w, h, rpp, passes, opt);
-  fs.writeFileSync(out, Buffer.from(res.pixel.buffer, res.pixel.byteOffset, res.pixel.byteLength));
+  writeFrame(out, res.pixel, w, h);
   fs.writeFileSync(out + ".radiance.f32", Buffer.from(res.radiance.buffer, res.radiance.byteOffset, res.radiance.byteLength));
   process.stderr.write(`rendered ${file} ${w}x${h} rpp ${rpp}, ${passes} pass(es), ${opt.granular ? (opt.fusion ? "kernel-by-kernel, passes fused by the runtime" : "kernel-by-kernel") : "fused"}: ${res.ms.toFixed(2)} ms on ${res.device}\n`);
 } else if (cmd === "pack-frame" || cmd === "frame") {
@@ -45,7 +54,7 @@ if (cmd === "pack") {
   const model = text === null ? null : /\.pdb$/i.test(rest[1]) ? { pdb: text } : JSON.parse(text);   // .pdb: Assign07's molecule mode
   const p = frame.packFrame(assign, model, +rest[2], +rest[3], +rest[4] || 2);
   if (cmd === "pack-frame") process.stdout.write(JSON.stringify(scene.packedToJSON(p)));
-  else { const px = frame.renderFrame(p); fs.writeFileSync(rest[5], Buffer.from(px.buffer, px.byteOffset, px.byteLength)); }
+  else writeFrame(rest[5], frame.renderFrame(p), +rest[2], +rest[3]);
 } else if (cmd === "ingest") {
   if (rest.length < 2) usage();
   const model = JSON.parse(fs.readFileSync(rest[0], "utf8").replace(/^\ufeff/, ""));
