@@ -32,6 +32,14 @@
 #define PT_AABB_UNSIGNED_ZERO 1   // single-cell sets only (their tmin / tmax / exits are compare-only): see slab1_fast
 #endif
 
+#ifndef PT_LANE_LISTS
+#define PT_LANE_LISTS 1          // optimistic kernel: single-cell triangle sets through per-lane candidate lists (pt_trace.hpp trace_cell1, LANES)
+#endif
+#ifndef PT_LANE_LISTS_GRIDS
+#define PT_LANE_LISTS_GRIDS 0    // ... in the grid kernels as well
+#endif
+#define PT_LANE_LISTS_FOR(FAST, GRIDS) ((FAST) && PT_LANE_LISTS && ((GRIDS) == 0 || PT_LANE_LISTS_GRIDS))
+
 namespace pt {
 
 // prepared triangle: 3 x float4 = {p0.xyz, n.x} {e1.xyz, n.y} {e2.xyz, n.z}
@@ -47,6 +55,10 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
     out[3u * i] = make_float4(p0.x, p0.y, p0.z, n.x);
     out[3u * i + 1] = make_float4(e1.x, e1.y, e1.z, n.y);
     out[3u * i + 2] = make_float4(e2.x, e2.y, e2.z, n.z);
+    float4* pn = (float4*)((char*)out + prepared_normals_offset(count));
+    pn[i] = make_float4(n.x, n.y, n.z, 0.0f);
+    if (i == count - 1u)
+        for (uint32_t k = count; (k & 3u) != 0u; ++k) pn[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto bad = [](float v) { const float a = __builtin_fabsf(v); return !(v == 0.0f || (a >= 9.094947e-13f && a <= 1.0995116e12f)); };
     // ... and every vertex / edge component within 2^21 in magnitude (NaN fails): the bounds of the set are the caller's word, the
     // finiteness arguments of the optimistic kernel (pt_trace.hpp) are about the triangles themselves
@@ -127,7 +139,7 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
         if (!GRIDS || S.n == 1u) {
             if (live) {
                 const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(ray, set_box(S));
-                if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, false, TRI_A10, FAST>(ray, bh, S) : trace_cell1<TRIANGLES, false, TRI_A10, FAST>(ray, bh, S);
+                if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, false, TRI_A10, FAST>(ray, bh, S) : trace_cell1<TRIANGLES, false, TRI_A10, FAST, false, PT_LANE_LISTS_FOR(FAST, GRIDS)>(ray, bh, S);
             }
         } else if (S.kind == KIND_TRIANGLES) {   // every lane of the wave enters: the tests of the walk are shared (pt_trace_coop.hpp)
             BoxHit bh = {};
@@ -200,7 +212,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
                 if (live) {
                     const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(sh, set_box(S));
                     if (bh.v) {
-                        ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, true, TRI_A10, FAST, true>(sh, bh, S) : trace_cell1<TRIANGLES, true, TRI_A10, FAST, true>(sh, bh, S);
+                        ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, true, TRI_A10, FAST, true>(sh, bh, S) : trace_cell1<TRIANGLES, true, TRI_A10, FAST, true, PT_LANE_LISTS_FOR(FAST, GRIDS)>(sh, bh, S);
                         walked = true;
                     }
                 }
@@ -243,7 +255,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 // FAST = false: the exact kernel (true divisions).  With `list` it recomputes the deferred samples; with list == nullptr it
 //               is the whole pass (geometry outside the guard, or PT_EXACT_FAST_DIV = 0).
 #ifndef PT_FUSED_WAVES_FAST
-#define PT_FUSED_WAVES_FAST 7   // the optimistic kernel without the grid walk: 72 VGPRs, no scratch (round 1, same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
+#define PT_FUSED_WAVES_FAST 6   // the optimistic kernel without the grid walk: 72 VGPRs, no scratch (round 1, same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
 #endif
 // GRIDS = 0    : every set is a single cell (n == 1: the reference's loose spheres and triangles, A10 code.js:399): only the
 //                wave-uniform loops are compiled in.  Without the DDA the register allocator needs 72 VGPRs and no scratch
@@ -265,13 +277,22 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;
     // GRIDS: the cell-offset tables of the grid sets (uint[n^3 + 1] each) are copied into LDS once per block, before any thread
     // leaves: launch_fused gave every set that fits a slot (GridArgs::lds_off).  The primitives themselves stay in memory.
-    if (GRIDS == 1) {
+    // PT_LANE_LISTS: likewise the prepared records of the single-cell triangle sets launch_fused gave a slot (the candidate loops fetch
+    // them per lane by ds_read_b128).
+    if (GRIDS == 1 || PT_LANE_LISTS_FOR(FAST, GRIDS)) {
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
-            if (S.n == 1u) continue;
-            const uint32_t words = S.n * S.n * S.n + 1u;
-            const uint32_t* src = (const uint32_t*)S.off;
-            for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
+            if (S.lds_off == kNoLds) continue;
+            if (S.n == 1u) {
+                if (!PT_LANE_LISTS_FOR(FAST, GRIDS)) continue;
+                const uint32_t words = S.nslots * 12u;
+                const uint32_t* src = (const uint32_t*)S.prims;
+                for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
+            } else if (GRIDS == 1) {
+                const uint32_t words = S.n * S.n * S.n + 1u;
+                const uint32_t* src = (const uint32_t*)S.off;
+                for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
+            }
         }
         __syncthreads();
     }
@@ -418,13 +439,29 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
         if (b.sets[i].n > 1u) { b.sets[i].lds_off = kCoopWordsPerBlock + (uint32_t)(used < kLdsOffWords ? used : kLdsOffWords); used += (uint64_t)b.sets[i].n * b.sets[i].n * b.sets[i].n + 1u; }
     }
     const bool staged = PT_STAGE_TABLES && used <= kLdsOffWords;
+    if (grids && !staged)
+        for (uint32_t i = 0; i < b.n_sets; ++i) b.sets[i].lds_off = kNoLds;
+    // ... then the prepared records of the single-cell triangle sets, for the candidate loops of the optimistic kernel: all that fit
+    // kLdsTriMax records, in upload order (a set without a slot runs the wave-uniform loop)
+    uint32_t tri_words = 0;
+    const uint32_t tri_base = grids ? kCoopWordsPerBlock + (staged ? (uint32_t)used : 0u) : 0u;   // multiples of 4 words: kCoopWordsPerBlock is, `used` is rounded up below
+    const uint32_t tri_base4 = (tri_base + 3u) & ~3u;
+    if (fast && PT_LANE_LISTS_FOR(true, grids ? 1 : 0)) {
+        for (uint32_t i = 0; i < b.n_sets; ++i) {
+            GridArgs& S = b.sets[i];
+            if (S.n != 1u || S.kind != KIND_TRIANGLES || !S.pnorm || S.nslots == 0u || tri_words / 12u + S.nslots > kLdsTriMax) continue;
+            S.lds_off = tri_base4 + tri_words;
+            tri_words += S.nslots * 12u;
+        }
+    }
     const dim3 grid((unsigned)((n + 255) / 256));
-    // dynamic LDS: the waves' exchange areas, then the staged tables (what the scene needs, not the 16 KB cap: occupancy)
-    const size_t lds2 = (size_t)kCoopWordsPerBlock * 4u, lds = lds2 + (staged ? (size_t)used * 4u : 0u);
+    // dynamic LDS: the waves' exchange areas, then the staged tables (what the scene needs, not the 16 KB cap: occupancy), then the staged triangles
+    const size_t lds_tri = tri_words ? (size_t)(tri_base4 - tri_base + tri_words) * 4u : 0u;
+    const size_t lds2 = (size_t)kCoopWordsPerBlock * 4u + lds_tri, lds = (size_t)kCoopWordsPerBlock * 4u + (staged ? (size_t)used * 4u : 0u) + lds_tri;
     if (fast) {
         if (grids && staged) hipLaunchKernelGGL((k_fusedPass<true, 1>), grid, dim3(256), lds, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
         else if (grids) hipLaunchKernelGGL((k_fusedPass<true, 2>), grid, dim3(256), lds2, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
-        else hipLaunchKernelGGL((k_fusedPass<true, 0>), grid, dim3(256), 0, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
+        else hipLaunchKernelGGL((k_fusedPass<true, 0>), grid, dim3(256), lds_tri, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
     } else {
         if (grids && staged) hipLaunchKernelGGL((k_fusedPass<false, 1>), grid, dim3(256), lds, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
         else if (grids) hipLaunchKernelGGL((k_fusedPass<false, 2>), grid, dim3(256), lds2, s, b, (uint32_t*)nullptr, redo_mask, redo_words);
@@ -436,7 +473,7 @@ void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint
     if (words) hipLaunchKernelGGL(k_deferCount, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, count);
 }
 
-size_t prepared_bytes(uint32_t count) { return (size_t)count * 48 + ((size_t)count + kTriGroup - 1) / kTriGroup * 16; }
+size_t prepared_bytes(uint32_t count) { return prepared_normals_offset(count) + (((size_t)count + 3) & ~(size_t)3) * 16; }
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word) {
     if (!count) return;
     hipLaunchKernelGGL(k_prepTriangles, dim3((count + 255) / 256), dim3(256), 0, s, (const float4*)pos, (float4*)out, count, insane_word);

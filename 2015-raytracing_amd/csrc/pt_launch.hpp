@@ -35,8 +35,11 @@ constexpr int kMaxMeshes = 16;
 
 constexpr uint32_t kNoLds = 0xFFFFFFFFu;
 constexpr uint32_t kLdsOffWords = 4096;   // 16 KB of LDS per block for cell-offset tables (n <= 15 for a single grid)
+constexpr uint32_t kLdsTriMax = 128;      // single-cell triangle sets staged in LDS for the per-lane candidate loops: 6 KB per block at most
 struct GridArgs {            // one cell-sorted primitive set, device pointers
     const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per PREPARED triangle (launch_prepTriangles)
+    const void* pnorm;       // triangles: float4 {n.xyz, 0} per prepared record, n = cross(e2, e1) -- the compact copy behind the records and
+                             // group spheres (prepared_normals_offset), read by scalar loads in the candidate sweep (pt_trace.hpp trace_cell1)
     const void* normals;     // 3 x float4 per triangle (null for spheres)
     const void* matid;       // uint per primitive (null: use `mesh_matid`)
     const void* off;         // uint[n^3 + 1]
@@ -46,8 +49,9 @@ struct GridArgs {            // one cell-sorted primitive set, device pointers
     uint32_t kind;           // KIND_SPHERES | KIND_TRIANGLES
     uint32_t fast_ok;        // geometry-side guard of the exact 3-operation divisions (pt_trace.hpp ray_recip): every bound is 0 or
                              // in [2^-30, 2^20]; for triangles every plane-normal component is 0 or in [2^-40, 2^40]
-    uint32_t lds_off;        // n > 1, fused pass: dword index of this set's cell-offset table inside the block's LDS copy, or
-                             // kNoLds when the tables of the scene do not fit (launch_fused assigns it)
+    uint32_t lds_off;        // fused pass (launch_fused assigns it).  n > 1: dword index of this set's cell-offset table inside the block's
+                             // LDS copy, or kNoLds when the tables of the scene do not fit.  n == 1, triangles: dword index (a multiple of
+                             // 4) of the set's `nslots` prepared records staged in LDS for the per-lane candidate loops, or kNoLds
     float delta[3], rdelta[3]; // n > 1, optimistic kernel: the cell width per axis (hi - lo) / n and its reciprocal, both correctly rounded --
     uint32_t nslots;         // off[n^3], the number of (cell, primitive) slots, when the host knows it (0: the walk reads it from the table)
     uint32_t walk_ok;        // what every lane would compute for itself from wave-uniform inputs (pt_trace.hpp axis_setup_t).  walk_ok: the
@@ -82,10 +86,17 @@ struct FusedArgs {
 void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words);
 bool fused_fast_available();   // compiled with PT_EXACT_FAST_DIV
 void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count);
-// {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip); `out` holds count records of 48 B and,
-// behind them, ceil(count / 8) float4 {centre, R'^2}: the bounding spheres of groups of 8 consecutive records
+// {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip); `out` holds count records of 48 B,
+// behind them ceil(count / kTriGroup) float4 {centre, R'^2}: the bounding spheres of groups of consecutive records, and behind those
+// count float4 {n, 0}: the plane normals alone
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word);
 size_t prepared_bytes(uint32_t count);   // what `out` must hold for `count` triangles
+#ifndef PT_TRI_GROUP
+#define PT_TRI_GROUP 16
+#endif
+constexpr uint32_t kTriGroup = PT_TRI_GROUP;   // prepared records per bounding sphere (pt_trace.hpp group_missed)
+// byte offset of the compact plane-normal array inside it: float4 {n, 0} per record, 64-byte aligned and zero-padded to a multiple of four records
+__host__ __device__ inline size_t prepared_normals_offset(uint32_t count) { return ((size_t)count * 48 + ((size_t)count + kTriGroup - 1) / kTriGroup * 16 + 63) & ~(size_t)63; }
 
 // ---- uniform-grid build on the device (pt_grid_build.hip) -------------------------------------------
 constexpr uint64_t kMaxGridSlots = 0x7FFFFFFFull;   // (cell, primitive) slots one grid may hold: the sort and every consumer index them with 31 bits

@@ -63,15 +63,37 @@ PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const f
     return ok != 0;
 }
 
+// The same test for the per-lane candidate loops of the optimistic kernel (trace_cell1, LANES): the lane already knows that the sign bit
+// of div is clear, and inside the guard windows (ray_guard, GridArgs::fast_ok) no operand of a comparison below can be a NaN except
+// gamma + beta = (+-inf) + (-+inf), where the infinite term of the offending sign already rejects: then
+//   !(beta < 0) & !(gamma < 0) & !(gb < 0)  ==  min3(beta, gamma, gb) >= 0      (v_min3_f32 drops the NaN, keeps the -inf)
+//   !(beta > 1) & !(gb > 1)                 ==  max(beta, gb) <= 1              (v_max_f32 likewise keeps the +inf)
+// -- five compares become two compares, one v_min3_f32 and one v_max_f32.  A lane outside the windows computes values nobody reads
+// (its sample is deferred to the exact kernel).
+PT_DEV bool tri_test_nn(f3 o, f3 d, float cmin, float cmax, const float4 A, const float4 B, const float4 C,
+                        float& t_out, float& beta_out, float& gamma_out) {
+    const f3 p0 = mk3(A.x, A.y, A.z), e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z), n = mk3(A.w, B.w, C.w);
+    const float div = dot3(n, d);
+    const float idiv = rcp_refined(div);
+    const f3 s = sub3(o, p0);
+    const float beta = dot3(cross3(s, d), e2) * idiv;
+    const float gamma = dot3(cross3(s, e1), d) * idiv;
+    const float gb = gamma + beta;
+    const float t = dot3(cross3(s, e2), e1) * -idiv;
+    const float lo = __builtin_fminf(__builtin_fminf(beta, gamma), gb);   // one v_min3_f32
+    const float hi = __builtin_fmaxf(beta, gb);
+    const int ok = (int)(div > 0.0f) & (int)(lo >= 0.0f) & (int)(hi <= 1.0f) & (int)(t >= cmin) & (int)(t <= cmax);
+    t_out = t;
+    beta_out = beta;
+    gamma_out = gamma;
+    return ok != 0;
+}
+
 // Groups of kTriGroup consecutive prepared triangles carry a bounding sphere {c, R'^2} behind the records (k_prepTriangles).  A ray whose
 // LINE passes the centre at more than R' misses every triangle of the group geometrically, by at least a hundredth of the group's radius:
 // far more than the rounding of the reference's barycentrics (relative 1e-6), so each of the reference's tests on them rejects
 // (A04 / A07 code.cl interTriangle) and skipping the group changes nothing.  |v x d|^2 = |v|^2 |d|^2 - (v.d)^2 is evaluated with its
 // cancellation error (<= 8 eps |v|^2 |d|^2) on the safe side; a NaN anywhere compares false = not missed.
-#ifndef PT_TRI_GROUP
-#define PT_TRI_GROUP 16
-#endif
-constexpr uint32_t kTriGroup = PT_TRI_GROUP;
 PT_DEV bool group_missed(const Ray& ray, float dd, const float4 g) {
     const f3 v = sub3(mk3(g.x, g.y, g.z), ray.o);
     const float b = v.x * ray.d.x + v.y * ray.d.y + v.z * ray.d.z;
@@ -236,12 +258,25 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     return a;
 }
 
+// The block's dynamic LDS (launch_fused sizes it): [cooperative-walk exchange area (pt_trace_coop.hpp)] [staged cell-offset tables]
+// [staged single-cell triangle sets]: GridArgs::lds_off indexes it.  The walks read it through THIS symbol, so the compiler knows the
+// address space and emits ds_read (through a generic pointer selected at run time it emitted flat_load pairs).
+extern __shared__ uint32_t pt_lds_dyn[];
+
 // One primitive set.  KIND / ANY as in pt_device.hpp.
 // trace_cell1: n == 1, a single cell, every lane walks the same list -> wave-uniform loop, scalar loads.
 // FLAG_ONLY (with ANY): the caller only asks whether the ray is blocked (the fused pass: sceneRender compares mint with maxt and nothing
 // else of the shadow ray survives the kernel).  The loop then keeps one flag instead of the hit record: idx != UINT32_MAX says blocked, t
 // is not delivered.
-template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false, bool FLAG_ONLY = false>
+// LANES (optimistic kernel, triangles, a set whose prepared records the block staged in LDS: S.lds_off): per-lane candidate lists.
+// The wave-uniform loop evaluates every test for every lane although the reference leaves half of them after five operations
+// (div <= 0: the triangle faces away, code.cl:256-260) -- on an incoherent wave some lane always needs the triangle, so the whole
+// wave pays for it.  Here a first wave-uniform sweep computes only div = dot(n, d) per triangle (n by scalar loads from the compact
+// normal array k_prepTriangles leaves behind the records) and shifts its sign bit into a per-lane word; then every lane walks ITS OWN
+// candidates -- sign bit clear -- in list order, fetching each record from LDS by ds_read_b128 (twelve-dword records: up to sixteen
+// distinct triangles are conflict-free).  In a closed room 5-7 of cornell.xml's 12 triangles survive the sweep.  Same predicates, same
+// arithmetic, same order within a lane (ties on t go to the lower index exactly as in the reference's loop).
+template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false, bool FLAG_ONLY = false, bool LANES = false>
 PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
@@ -272,6 +307,45 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
     const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
     bool done = false;
+    if (LANES && KIND == TRIANGLES && FAST && RULE == TRI_A10 && S.lds_off != kNoLds && begin == 0u) {
+        struct alignas(64) N4 { float4 n[4]; };   // four plane normals per s_load_dwordx16 (the array is padded to a multiple of four, zero-filled)
+        const N4* __restrict__ pn = (const N4*)S.pnorm;
+        const uint32_t lds_bytes = S.lds_off * 4u;
+        for (uint32_t c0 = 0u; c0 < end; c0 += 32u) {
+            const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u, quads = (cnt + 3u) >> 2;
+            uint32_t neg = 0u;
+            for (uint32_t g = 0; g < quads; ++g) {
+                const N4 v = pn[(c0 >> 2) + g];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(dot3(mk3(v.n[k].x, v.n[k].y, v.n[k].z), ray.d)), 31);   // (neg << 1) | sign(div)
+            }
+            // triangle c0 + k at bit 31 - k; the padding of the last quad (div = 0: sign clear) is masked off
+            uint32_t cand = (~neg << (32u - 4u * quads)) & (0xFFFFFFFFu << (32u - cnt));
+            if (ANY && done) cand = 0u;            // (a set of more than 32 triangles: a blocked lane sits the later sweeps out)
+            while (cand != 0u) {
+                const uint32_t k = (uint32_t)__builtin_clz(cand);
+                cand &= ~(0x80000000u >> k);
+                const uint32_t i = c0 + k;
+                const float4* __restrict__ q = (const float4*)((const char*)pt_lds_dyn + (lds_bytes + __umul24(i, 48u)));
+                float ti, b, gm;
+                const bool hit = tri_test_nn(ray.o, ray.d, cmin, cmax, q[0], q[1], q[2], ti, b, gm);
+                if (ANY && FLAG_ONLY) {
+                    if (hit && ti < ray.maxt) { done = true; cand = 0u; }
+                    continue;
+                }
+                const bool better = (int)hit & (int)(ti < ch.t);
+                ch.t = better ? ti : ch.t;
+                ch.idx = better ? i : ch.idx;
+                ch.beta = better ? b : ch.beta;
+                ch.gamma = better ? gm : ch.gamma;
+                if (ANY && better) { done = true; cand = 0u; }
+            }
+            if (ANY && __builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        }
+        if (ANY && FLAG_ONLY && done) ch.idx = 0u;
+        return ch;
+    }
     const float4* __restrict__ p = prims + (size_t)begin * (KIND == SPHERES ? 1u : 3u);   // one running pointer: immediate-offset scalar loads
 #if PT_UNROLL_UNIFORM > 1
 #pragma unroll PT_UNROLL_UNIFORM
@@ -303,11 +377,9 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     return ch;
 }
 
-// The fused pass stages the cell-offset tables of its grid sets in the block's dynamic LDS (launch_fused sizes it).  The walk reads them
-// through THIS symbol, so the compiler knows the address space and emits ds_read (through a generic pointer selected at run time against
-// the global table it emitted flat_load pairs).  LDS_TABLES is a template parameter for the same reason: k_fusedPass<*, 1> has every
-// table staged, k_fusedPass<*, 2> (a scene whose tables do not fit) reads them all from memory.
-extern __shared__ uint32_t pt_lds_dyn[];   // [cooperative-walk exchange area (pt_trace_coop.hpp)] [staged tables]: GridArgs::lds_off indexes it
+// The fused pass stages the cell-offset tables of its grid sets in the block's dynamic LDS.  LDS_TABLES is a template parameter because
+// a run-time choice of address space degenerates into flat loads: k_fusedPass<*, 1> has every table staged, k_fusedPass<*, 2> (a scene
+// whose tables do not fit) reads them all from memory.
 // cell -> [begin, end) of a grid set: one 8-byte LDS read when the table is staged, else two dwords from memory
 template <bool LDS_TABLES>
 PT_DEV void cell_range(const GridArgs& S, const uint32_t* __restrict__ off, uint32_t cell, uint32_t& i, uint32_t& end) {
