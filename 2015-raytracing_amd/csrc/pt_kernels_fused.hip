@@ -106,18 +106,22 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
 #endif
 #define PT_PARK_PN_FOR(GRIDS) (PT_PARK_PN || (PT_PARK_PN_GRIDS && (GRIDS) != 0))
 #define PT_PARK_WORDS(GRIDS) (PT_PARK_PN_FOR(GRIDS) ? 13 : 7)
-struct Park {
-#if PT_PARK_LDS
-    float* base;   // &park[0][threadIdx.x]
-    PT_DEV void put(int w, float v) const { base[w * 256] = v; }
-    PT_DEV float get(int w) const { return base[w * 256]; }
+// STRIDE: words between the rows of one lane's record ([word][lane] rows of 256 lanes in k_fusedPass).  ATTE_LDS: the attenuation is
+// parked too (else it stays in registers and the p / n rows move up).
+template <int STRIDE, bool ATTE_LDS>
+struct ParkT {
+    static constexpr bool kAtteLds = ATTE_LDS;
+    static constexpr int kP = ATTE_LDS ? 7 : 4, kN = kP + 3;
+    float* base;   // the lane's word 0
+    PT_DEV void put(int w, float v) const { base[w * STRIDE] = v; }
+    PT_DEV float get(int w) const { return base[w * STRIDE]; }
     PT_DEV void acc_add(float x, float y, float z) const {
         put(0, get(0) + x); put(1, get(1) + y); put(2, get(2) + z); put(3, get(3) + 1.0f);
     }
-    PT_DEV void put_pn(const Poi& q) const { put(7, q.p.x); put(8, q.p.y); put(9, q.p.z); put(10, q.n.x); put(11, q.n.y); put(12, q.n.z); }
-    PT_DEV void get_pn(Poi& q) const { q.p = mk3(get(7), get(8), get(9)); q.n = mk3(get(10), get(11), get(12)); }
-#endif
+    PT_DEV void put_pn(const Poi& q) const { put(kP, q.p.x); put(kP + 1, q.p.y); put(kP + 2, q.p.z); put(kN, q.n.x); put(kN + 1, q.n.y); put(kN + 2, q.n.z); }
+    PT_DEV void get_pn(Poi& q) const { q.p = mk3(get(kP), get(kP + 1), get(kP + 2)); q.n = mk3(get(kN), get(kN + 1), get(kN + 2)); }
 };
+typedef ParkT<256, true> Park;
 
 PT_DEV Box set_box(const GridArgs& S) {
     Box b;
@@ -128,8 +132,8 @@ PT_DEV Box set_box(const GridArgs& S) {
 
 // closest hit over every set in upload order, z-buffered through ray.maxt
 // (A10 code.cl:675-800, 802-935, 937-1070; order A10 code.js:1809-1813)
-template <bool FAST, int GRIDS>
-PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park, bool& defer) {
+template <bool FAST, int GRIDS, class PARK>
+PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const PARK& park, bool& defer) {
     if (FAST && !(ray.mint == ray.maxt)) defer = defer || !ray_guard(ray);   // a dead ray divides nothing
     for (uint32_t s = 0; s < A.n_sets; ++s) {
         const GridArgs& S = A.sets[s];
@@ -169,8 +173,8 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const Park& park
 
 // per light: shadow ray, any-hit over every set, shade (A10 code.js:1817-1826; code.cl:631-673,
 // 1073-1321, 1323-1364)
-template <bool FAST, int GRIDS>
-PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc, const Park& park, bool& defer) {
+template <bool FAST, int GRIDS, class PARK>
+PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc, const PARK& park, bool& defer) {
     const float4* material = (const float4*)A.material;
     for (uint32_t l = 0; l < A.n_lights; ++l) {
         const LightArgs& L = A.lights[l];
@@ -236,15 +240,76 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
         float4 c4 = material[poi.matId];
 #if PT_PARK_LDS
         if (PT_PARK_PN_FOR(GRIDS)) park.get_pn(poi);
-        poi.atte = mk3(park.get(4), park.get(5), park.get(6));
+        if (PARK::kAtteLds) poi.atte = mk3(park.get(4), park.get(5), park.get(6));
         f3 c = shade_vertex(poi, sh, mk3(c4.x, c4.y, c4.z), ld3(L.scene), ld3(L.scene + 3), ld3(L.scene + 6), L.scene[9]);
-        park.put(4, poi.atte.x); park.put(5, poi.atte.y); park.put(6, poi.atte.z);
+        if (PARK::kAtteLds) { park.put(4, poi.atte.x); park.put(5, poi.atte.y); park.put(6, poi.atte.z); }
         park.acc_add(c.x, c.y, c.z);
 #else
         f3 c = shade_vertex(poi, sh, mk3(c4.x, c4.y, c4.z), ld3(L.scene), ld3(L.scene + 3), ld3(L.scene + 6), L.scene[9]);
         acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
 #endif
     }
+}
+
+// Block prologue of the fused kernels.  GRIDS: the cell-offset tables of the grid sets (uint[n^3 + 1] each) are copied into LDS once
+// per block, before any thread leaves: launch_fused gave every set that fits a slot (GridArgs::lds_off).  The primitives of a grid stay
+// in memory.  PT_LANE_LISTS: likewise the prepared records of the single-cell triangle sets launch_fused gave a slot (the candidate
+// loops fetch them per lane by ds_read_b128).
+template <bool FAST, int GRIDS>
+PT_DEV void stage_block(const FusedArgs& A) {
+    if (GRIDS == 1 || PT_LANE_LISTS_FOR(FAST, GRIDS)) {
+        for (uint32_t s = 0; s < A.n_sets; ++s) {
+            const GridArgs& S = A.sets[s];
+            if (S.lds_off == kNoLds) continue;
+            if (S.n == 1u) {
+                if (!PT_LANE_LISTS_FOR(FAST, GRIDS)) continue;
+                const uint32_t words = S.nslots * 12u;
+                const uint32_t* src = (const uint32_t*)S.prims;
+                for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
+            } else if (GRIDS == 1) {
+                const uint32_t words = S.n * S.n * S.n + 1u;
+                const uint32_t* src = (const uint32_t*)S.off;
+                for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// initTrace (code.cl:458-543) for one ray id of the tile: thin-lens ray through its pixel, clipped to the scene box
+PT_DEV Ray primary_ray(const FusedArgs& A, uint64_t lid) {
+    const uint64_t lpix = lid / A.rpp;
+    const uint32_t smp = (uint32_t)(lid - lpix * A.rpp);
+    const uint32_t lrow = (uint32_t)(lpix / A.width);
+    const uint32_t col = (uint32_t)(lpix - (uint64_t)lrow * A.width);
+    const uint32_t row = A.row0 + lrow;
+    Cam cam;
+    cam.eye = ld3(A.cam); cam.U = ld3(A.cam + 3); cam.V = ld3(A.cam + 6); cam.W = ld3(A.cam + 9);
+    cam.width = A.cam[12]; cam.height = A.cam[13];
+    cam.cols = f2u(A.cam[14]); cam.rows = f2u(A.cam[15]);
+    Box bound;
+    bound.lo = mk3(A.bound[0], A.bound[1], A.bound[2]);
+    bound.hi = mk3(A.bound[4], A.bound[5], A.bound[6]);
+    const f3 fp = focal_point(cam, (float)col, (float)row, A.focal_length);
+    float cx, cy;
+    if (A.rpp > 1) {
+        // un-jittered k x k lens grid; coordinates accumulate by repeated addition in the
+        // reference (coord += delta), so they are rebuilt the same way
+        const uint32_t side = f2u(cl_sqrt((float)A.rpp));
+        const float delta = 1.0f / (float)side;
+        const uint32_t i = smp / side, j = smp - i * side;
+        cy = delta / 2.0f;
+        for (uint32_t k = 0; k < i; ++k) cy += delta;
+        cx = delta / 2.0f;
+        for (uint32_t k = 0; k < j; ++k) cx += delta;
+    } else {
+        float2 c = ((const float2*)A.uv)[lpix];
+        cx = c.x;
+        cy = c.y;
+    }
+    Ray ray = thin_lens_ray(cam, fp, A.lens_rad, cx, cy);
+    clip_to(ray, bound);
+    return ray;
 }
 
 #ifndef PT_FUSED_WAVES
@@ -275,27 +340,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 template <bool FAST, int GRIDS>
 __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES)) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words) {
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;
-    // GRIDS: the cell-offset tables of the grid sets (uint[n^3 + 1] each) are copied into LDS once per block, before any thread
-    // leaves: launch_fused gave every set that fits a slot (GridArgs::lds_off).  The primitives themselves stay in memory.
-    // PT_LANE_LISTS: likewise the prepared records of the single-cell triangle sets launch_fused gave a slot (the candidate loops fetch
-    // them per lane by ds_read_b128).
-    if (GRIDS == 1 || PT_LANE_LISTS_FOR(FAST, GRIDS)) {
-        for (uint32_t s = 0; s < A.n_sets; ++s) {
-            const GridArgs& S = A.sets[s];
-            if (S.lds_off == kNoLds) continue;
-            if (S.n == 1u) {
-                if (!PT_LANE_LISTS_FOR(FAST, GRIDS)) continue;
-                const uint32_t words = S.nslots * 12u;
-                const uint32_t* src = (const uint32_t*)S.prims;
-                for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
-            } else if (GRIDS == 1) {
-                const uint32_t words = S.n * S.n * S.n + 1u;
-                const uint32_t* src = (const uint32_t*)S.off;
-                for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
-            }
-        }
-        __syncthreads();
-    }
+    stage_block<FAST, GRIDS>(A);
     // Exact kernel in redo mode (`redo_mask`: the bits the optimistic kernel set): one thread per 32-sample word, a loop over its
     // set bits -- no list, no count, no host round trip between the two kernels.  Otherwise: one thread, one sample, one trip.
     // GRIDS: the walk shares its triangle tests across the wave (pt_trace_coop.hpp), so every lane stays in to the end: a lane
@@ -322,20 +367,6 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
         lid = n_local - 1u;
     }
     bool defer = false;
-    const uint64_t lpix = lid / A.rpp;
-    const uint32_t smp = (uint32_t)(lid - lpix * A.rpp);
-    const uint32_t lrow = (uint32_t)(lpix / A.width);
-    const uint32_t col = (uint32_t)(lpix - (uint64_t)lrow * A.width);
-    const uint32_t row = A.row0 + lrow;
-
-    Cam cam;
-    cam.eye = ld3(A.cam); cam.U = ld3(A.cam + 3); cam.V = ld3(A.cam + 6); cam.W = ld3(A.cam + 9);
-    cam.width = A.cam[12]; cam.height = A.cam[13];
-    cam.cols = f2u(A.cam[14]); cam.rows = f2u(A.cam[15]);
-    Box bound;
-    bound.lo = mk3(A.bound[0], A.bound[1], A.bound[2]);
-    bound.hi = mk3(A.bound[4], A.bound[5], A.bound[6]);
-
     int32_t seed = A.seeds[lid];
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // initAcu (A10 code.cl:448-456) when the pass is a frame's first
     if (!A.fresh) acc = ((const float4*)A.acu)[lid];
@@ -346,27 +377,7 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     park.put(0, acc.x); park.put(1, acc.y); park.put(2, acc.z); park.put(3, acc.w);
     park.put(4, 1.0f); park.put(5, 1.0f); park.put(6, 1.0f);
 #endif
-
-    // ---- initTrace (code.cl:458-543) for this one ray
-    f3 fp = focal_point(cam, (float)col, (float)row, A.focal_length);
-    float cx, cy;
-    if (A.rpp > 1) {
-        // un-jittered k x k lens grid; coordinates accumulate by repeated addition in the
-        // reference (coord += delta), so they are rebuilt the same way
-        const uint32_t side = f2u(cl_sqrt((float)A.rpp));
-        const float delta = 1.0f / (float)side;
-        const uint32_t i = smp / side, j = smp - i * side;
-        cy = delta / 2.0f;
-        for (uint32_t k = 0; k < i; ++k) cy += delta;
-        cx = delta / 2.0f;
-        for (uint32_t k = 0; k < j; ++k) cx += delta;
-    } else {
-        float2 c = ((const float2*)A.uv)[lpix];
-        cx = c.x;
-        cy = c.y;
-    }
-    Ray ray = thin_lens_ray(cam, fp, A.lens_rad, cx, cy);
-    clip_to(ray, bound);
+    Ray ray = primary_ray(A, lid);
     Poi poi;
     poi.p = mk3(0.0f, 0.0f, 0.0f);
     poi.n = mk3(0.0f, 0.0f, 0.0f);
@@ -386,7 +397,7 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
                 ray.maxt = PT_INF;
             }
         }
-        closest_all<FAST, GRIDS>(A, ray, poi, park, defer);
+        closest_all<FAST, GRIDS, Park>(A, ray, poi, park, defer);
         if (seg == 0) {
             for (uint32_t l = 0; l < A.n_lights; ++l) {  // lightRender (code.cl:600-629), primary segment only
                 if (ray.mint == ray.maxt) continue;
@@ -403,7 +414,7 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
 #endif
             }
         }
-        direct_all<FAST, GRIDS>(A, poi, seed, acc, park, defer);
+        direct_all<FAST, GRIDS, Park>(A, poi, seed, acc, park, defer);
     }
 
     if (FAST && defer) {   // hand the sample to the exact kernel: its inputs stay as they were
@@ -419,6 +430,7 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     ((float4*)A.acu)[lid] = acc;
   }
 }
+
 
 // deferred-sample bookkeeping: count the set bits (only when the host asks, mirt_pass_deferred)
 __global__ void __launch_bounds__(256) k_deferCount(const uint32_t* mask, uint32_t words, uint32_t* count) {

@@ -16,6 +16,20 @@ namespace pt {
 
 struct Hit { uint32_t idx; float t, beta, gamma; };
 
+// Geometry the kernels only read, fetched in wave-uniform loops: through the CONSTANT address space, so the loads stay scalar
+// (s_load_dwordx4 / x16 into SGPRs) wherever the address is uniform.  Through a plain global pointer the back end may only use a scalar
+// load when nothing in the kernel can have stored to memory before it: a kernel that writes results inside its main loop (the
+// compacting variant, profiles/experiments/wave_queue_compaction.patch) silently got per-lane global_loads for every geometry read
+// after the first store.  The scene buffers are never written by a pass.
+#define PT_CONST_AS __attribute__((address_space(4)))
+typedef float pt_v4f __attribute__((ext_vector_type(4)));
+typedef float pt_v16f __attribute__((ext_vector_type(16)));
+PT_DEV float4 ldc4(const void* base, size_t idx) {   // float4 number idx of a read-only array
+    const pt_v4f v = ((const pt_v4f PT_CONST_AS*)base)[idx];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+PT_DEV uint32_t ldc_u32(const void* base, size_t idx) { return ((const uint32_t PT_CONST_AS*)base)[idx]; }
+
 // Moeller-Trumbore on a prepared triangle; same operations, same order and the same
 // accept/reject predicates as the reference's interTriangle (A10 code.cl:250-288), written without early exits:
 // in a wave-uniform loop the 64 lanes leave at different tests anyway.
@@ -278,8 +292,6 @@ extern __shared__ uint32_t pt_lds_dyn[];
 // arithmetic, same order within a lane (ties on t go to the lower index exactly as in the reference's loop).
 template <int KIND, bool ANY, int RULE = TRI_A10, bool FAST = false, bool FLAG_ONLY = false, bool LANES = false>
 PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
-    const float4* __restrict__ prims = (const float4*)S.prims;
-    const uint32_t* __restrict__ off = (const uint32_t*)S.off;
     Hit ch;
     ch.idx = UINT32_MAX;
     ch.t = ray.maxt;
@@ -304,21 +316,20 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     }
     const float cmin = bh.tmin;
     const float cmax = cl_min(cl_min(tn[0], tn[1]), tn[2]);   // one v_min3_f32
-    const uint32_t begin = __builtin_amdgcn_readfirstlane(off[0]);
-    const uint32_t end = __builtin_amdgcn_readfirstlane(off[1]);
+    const uint32_t begin = __builtin_amdgcn_readfirstlane(ldc_u32(S.off, 0));
+    const uint32_t end = __builtin_amdgcn_readfirstlane(ldc_u32(S.off, 1));
     bool done = false;
     if (LANES && KIND == TRIANGLES && FAST && RULE == TRI_A10 && S.lds_off != kNoLds && begin == 0u) {
-        struct alignas(64) N4 { float4 n[4]; };   // four plane normals per s_load_dwordx16 (the array is padded to a multiple of four, zero-filled)
-        const N4* __restrict__ pn = (const N4*)S.pnorm;
+        const pt_v16f PT_CONST_AS* pn = (const pt_v16f PT_CONST_AS*)S.pnorm;   // four plane normals per s_load_dwordx16 (the array is padded to a multiple of four, zero-filled)
         const uint32_t lds_bytes = S.lds_off * 4u;
         for (uint32_t c0 = 0u; c0 < end; c0 += 32u) {
             const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u, quads = (cnt + 3u) >> 2;
             uint32_t neg = 0u;
             for (uint32_t g = 0; g < quads; ++g) {
-                const N4 v = pn[(c0 >> 2) + g];
+                const pt_v16f v = pn[(c0 >> 2) + g];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(dot3(mk3(v.n[k].x, v.n[k].y, v.n[k].z), ray.d)), 31);   // (neg << 1) | sign(div)
+                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(dot3(mk3(v[4 * k], v[4 * k + 1], v[4 * k + 2]), ray.d)), 31);   // (neg << 1) | sign(div)
             }
             // triangle c0 + k at bit 31 - k; the padding of the last quad (div = 0: sign clear) is masked off
             uint32_t cand = (~neg << (32u - 4u * quads)) & (0xFFFFFFFFu << (32u - cnt));
@@ -346,7 +357,7 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         if (ANY && FLAG_ONLY && done) ch.idx = 0u;
         return ch;
     }
-    const float4* __restrict__ p = prims + (size_t)begin * (KIND == SPHERES ? 1u : 3u);   // one running pointer: immediate-offset scalar loads
+    const pt_v4f PT_CONST_AS* p = (const pt_v4f PT_CONST_AS*)S.prims + (size_t)begin * (KIND == SPHERES ? 1u : 3u);   // one running pointer: immediate-offset scalar loads
 #if PT_UNROLL_UNIFORM > 1
 #pragma unroll PT_UNROLL_UNIFORM
 #endif
@@ -354,9 +365,9 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         float ti, b = 0.0f, gm = 0.0f;
         bool hit;
         if (KIND == SPHERES) {
-            hit = sph_test(ray.o, ray.d, sr, cmin, cmax, p[0], ti);
+            hit = sph_test(ray.o, ray.d, sr, cmin, cmax, ldc4((const void*)p, 0), ti);
         } else {
-            hit = tri_test<RULE, FAST, PT_UNIFORM_CULL != 0>(ray.o, ray.d, cmin, cmax, p[0], p[1], p[2], ti, b, gm);
+            hit = tri_test<RULE, FAST, PT_UNIFORM_CULL != 0>(ray.o, ray.d, cmin, cmax, ldc4((const void*)p, 0), ldc4((const void*)p, 1), ldc4((const void*)p, 2), ti, b, gm);
         }
         if (ANY && FLAG_ONLY) {
             done = done | ((int)hit & (int)(ti < ray.maxt));   // the first hit ends the reference's loop: ch.t is still maxt when it is compared
