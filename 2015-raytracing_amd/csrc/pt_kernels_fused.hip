@@ -55,10 +55,20 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
     out[3u * i] = make_float4(p0.x, p0.y, p0.z, n.x);
     out[3u * i + 1] = make_float4(e1.x, e1.y, e1.z, n.y);
     out[3u * i + 2] = make_float4(e2.x, e2.y, e2.z, n.z);
+    // the candidate sweep's array (pt_trace.hpp trace_cell1): {n, k = p0 . n} and the margin constants of the plane window,
+    // M = G |o|_1 + H = 2^-17 |e1|_1 |e2|_1 (|o|_1 + |p0|_1), each product rounded up, H at least 2^-56
     float4* pn = (float4*)((char*)out + prepared_normals_offset(count));
-    pn[i] = make_float4(n.x, n.y, n.z, 0.0f);
+    {
+        const float up = 1.0000002384185791015625f;   // 1 + 2^-22: more than the rounding of the sums and products below
+        const float k = (float)((double)p0.x * n.x + (double)p0.y * n.y + (double)p0.z * n.z);
+        const float E = ((__builtin_fabsf(e1.x) + __builtin_fabsf(e1.y) + __builtin_fabsf(e1.z)) * up) * ((__builtin_fabsf(e2.x) + __builtin_fabsf(e2.y) + __builtin_fabsf(e2.z)) * up) * up;
+        const float G = 0x1p-17f * E;
+        const float H = __builtin_fmaxf(G * ((__builtin_fabsf(p0.x) + __builtin_fabsf(p0.y) + __builtin_fabsf(p0.z)) * up) * up, 0x1p-56f);
+        pn[2u * i] = make_float4(n.x, n.y, n.z, k);
+        pn[2u * i + 1] = make_float4(G, H, 0.0f, 0.0f);
+    }
     if (i == count - 1u)
-        for (uint32_t k = count; (k & 3u) != 0u; ++k) pn[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 2u * count; (k & 7u) != 0u; ++k) pn[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto bad = [](float v) { const float a = __builtin_fabsf(v); return !(v == 0.0f || (a >= 9.094947e-13f && a <= 1.0995116e12f)); };
     // ... and every vertex / edge component within 2^21 in magnitude (NaN fails): the bounds of the set are the caller's word, the
     // finiteness arguments of the optimistic kernel (pt_trace.hpp) are about the triangles themselves
@@ -320,7 +330,7 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint64_t lid) {
 // FAST = false: the exact kernel (true divisions).  With `list` it recomputes the deferred samples; with list == nullptr it
 //               is the whole pass (geometry outside the guard, or PT_EXACT_FAST_DIV = 0).
 #ifndef PT_FUSED_WAVES_FAST
-#define PT_FUSED_WAVES_FAST 6   // the optimistic kernel without the grid walk: 72 VGPRs, no scratch (round 1, same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
+#define PT_FUSED_WAVES_FAST 7   // the optimistic kernel without the grid walk: 72 VGPRs, no scratch (round 1, same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
 #endif
 // GRIDS = 0    : every set is a single cell (n == 1: the reference's loose spheres and triangles, A10 code.js:399): only the
 //                wave-uniform loops are compiled in.  Without the DDA the register allocator needs 72 VGPRs and no scratch
@@ -417,6 +427,13 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
         direct_all<FAST, GRIDS, Park>(A, poi, seed, acc, park, defer);
     }
 
+    if (FAST && !GRIDS) {
+        // the ray id again, from the thread index (one sample per thread in this kernel): re-deriving it here costs two instructions,
+        // keeping it (and the two 64-bit addresses made from it) alive across the whole path cost four spilled registers at 7 waves
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        lid = (uint64_t)blockIdx.x * 256u + t;
+    }
     if (FAST && defer) {   // hand the sample to the exact kernel: its inputs stay as they were
         if (valid) atomicOr(&defer_mask[lid >> 5], 1u << (lid & 31u));
         if (!GRIDS) return;
@@ -485,7 +502,7 @@ void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint
     if (words) hipLaunchKernelGGL(k_deferCount, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, count);
 }
 
-size_t prepared_bytes(uint32_t count) { return prepared_normals_offset(count) + (((size_t)count + 3) & ~(size_t)3) * 16; }
+size_t prepared_bytes(uint32_t count) { return prepared_normals_offset(count) + (((size_t)count + 3) & ~(size_t)3) * 32; }
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word) {
     if (!count) return;
     hipLaunchKernelGGL(k_prepTriangles, dim3((count + 255) / 256), dim3(256), 0, s, (const float4*)pos, (float4*)out, count, insane_word);

@@ -47,6 +47,9 @@ enum TriRule { TRI_A10 = 0, TRI_A07 = 1, TRI_A04 = 2 };
 #ifndef PT_UNIFORM_CULL
 #define PT_UNIFORM_CULL 0
 #endif
+#ifndef PT_LANE_FILTER
+#define PT_LANE_FILTER 1   // the candidate sweep of trace_cell1 also drops triangles whose plane the ray meets outside its window
+#endif
 // WAVE_CULL (the wave-uniform loops: all lanes hold the SAME triangle): when the triangle faces away from every lane's ray
 // (div <= 0 in all of them: coherent primary and shadow rays against half of a closed room's walls) the rest of the test is skipped for the
 // wave -- the reference's first early-out (code.cl:259), taken when the whole wave takes it.
@@ -285,8 +288,8 @@ extern __shared__ uint32_t pt_lds_dyn[];
 // LANES (optimistic kernel, triangles, a set whose prepared records the block staged in LDS: S.lds_off): per-lane candidate lists.
 // The wave-uniform loop evaluates every test for every lane although the reference leaves half of them after five operations
 // (div <= 0: the triangle faces away, code.cl:256-260) -- on an incoherent wave some lane always needs the triangle, so the whole
-// wave pays for it.  Here a first wave-uniform sweep computes only div = dot(n, d) per triangle (n by scalar loads from the compact
-// normal array k_prepTriangles leaves behind the records) and shifts its sign bit into a per-lane word; then every lane walks ITS OWN
+// wave pays for it.  Here a first wave-uniform sweep computes div = dot(n, d) per triangle (n by scalar loads from the compact
+// array k_prepTriangles leaves behind the records) and shifts a sign bit into a per-lane word; then every lane walks ITS OWN
 // candidates -- sign bit clear -- in list order, fetching each record from LDS by ds_read_b128 (twelve-dword records: up to sixteen
 // distinct triangles are conflict-free).  In a closed room 5-7 of cornell.xml's 12 triangles survive the sweep.  Same predicates, same
 // arithmetic, same order within a lane (ties on t go to the lower index exactly as in the reference's loop).
@@ -320,16 +323,47 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     const uint32_t end = __builtin_amdgcn_readfirstlane(ldc_u32(S.off, 1));
     bool done = false;
     if (LANES && KIND == TRIANGLES && FAST && RULE == TRI_A10 && S.lds_off != kNoLds && begin == 0u) {
-        const pt_v16f PT_CONST_AS* pn = (const pt_v16f PT_CONST_AS*)S.pnorm;   // four plane normals per s_load_dwordx16 (the array is padded to a multiple of four, zero-filled)
+        // the sweep's array: two float4 per triangle, {n.xyz, k = p0.n} {G, H, 0, 0} (k_prepTriangles), two triangles per s_load_dwordx16;
+        // padded to a multiple of four triangles, zero-filled
+        const pt_v16f PT_CONST_AS* pn = (const pt_v16f PT_CONST_AS*)S.pnorm;
         const uint32_t lds_bytes = S.lds_off * 4u;
+#if PT_LANE_FILTER
+        // PLANE WINDOW (the second filter of the sweep).  A hit needs cmin <= t <= cmax and t < maxt (code.cl:273-280 and the callers'
+        // comparisons), where the reference's t = fl(dot(cross(s, e2), e1) * -(1 / div)).  In exact arithmetic that numerator is
+        // s . (e2 x e1) = o . n - p0 . n, which the sweep gets in three fused operations: sn = fma(n.z, o.z, fma(n.y, o.y, fma(n.x, o.x, -k))).
+        // Both evaluations stay within 14 u E (|o|_1 + |p0|_1) of each other (u = 2^-24, E = |e1|_1 |e2|_1: the rounding of s, of the two
+        // cross products, of the dot products, of n and of k, term by term); the sweep allows M = 2^-17 E (|o|_1 + |p0|_1), nine times
+        // that, never less than 2^-56, and widens the window by 2^-20 relative, which also covers the three roundings between the
+        // reference's numerator and its t and those of the two tests below.  With div > 0:
+        //   -sn - M > hi+ * div,  hi+ = max(min(cmax, maxt) * (1 + 2^-20), 2^-100)   =>   the reference's t > min(cmax, maxt): no hit
+        //   -sn + M < lo- * div,  lo- = cmin * (1 - 2^-20)                            =>   the reference's t < cmin, and at least
+        //        2^-57 / 2^82 in magnitude when cmin = 0 (no underflow to a -0 that would pass t >= 0): no hit
+        // so such a triangle is not a candidate: every test the lane skips is one the reference's own window rejects, and the tests it
+        // does run are the reference's.  min3 drops a NaN operand (then the triangle stays a candidate); lanes outside the guard
+        // windows are deferred to the exact kernel whatever they compute here.  In cornell.xml a closest query keeps 2-4 of the 5-7
+        // front-facing triangles (the wall the ray leaves through, sometimes the free-standing triangle's plane), a shadow query 0-2.
+        const float o1 = __builtin_fabsf(ray.o.x) + __builtin_fabsf(ray.o.y) + __builtin_fabsf(ray.o.z);
+        const float hi_p = __builtin_fmaxf(__builtin_fminf(cmax, ray.maxt) * 1.00000095367431640625f, 0x1p-100f);
+        const float lo_m = cmin * 0.99999904632568359375f;
+#endif
         for (uint32_t c0 = 0u; c0 < end; c0 += 32u) {
             const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u, quads = (cnt + 3u) >> 2;
             uint32_t neg = 0u;
-            for (uint32_t g = 0; g < quads; ++g) {
-                const pt_v16f v = pn[(c0 >> 2) + g];
+            for (uint32_t g = 0; g < 2u * quads; ++g) {
+                const pt_v16f v = pn[(c0 >> 1) + g];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(dot3(mk3(v[4 * k], v[4 * k + 1], v[4 * k + 2]), ray.d)), 31);   // (neg << 1) | sign(div)
+                for (int k = 0; k < 2; ++k) {
+                    const float div = dot3(mk3(v[8 * k], v[8 * k + 1], v[8 * k + 2]), ray.d);
+#if PT_LANE_FILTER
+                    const float sn = cl_fma(v[8 * k + 2], ray.o.z, cl_fma(v[8 * k + 1], ray.o.y, cl_fma(v[8 * k], ray.o.x, -v[8 * k + 3])));
+                    const float M = cl_fma(v[8 * k + 4], o1, v[8 * k + 5]);
+                    const float c = cl_fma(hi_p, div, sn + M), a = cl_fma(lo_m, div, sn - M);
+                    const float w = __builtin_fminf(__builtin_fminf(div, c), -a);   // one v_min3_f32; negative: not a candidate
+#else
+                    const float w = div;
+#endif
+                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(w), 31);   // (neg << 1) | sign
+                }
             }
             // triangle c0 + k at bit 31 - k; the padding of the last quad (div = 0: sign clear) is masked off
             uint32_t cand = (~neg << (32u - 4u * quads)) & (0xFFFFFFFFu << (32u - cnt));
