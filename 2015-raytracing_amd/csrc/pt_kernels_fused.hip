@@ -145,6 +145,7 @@ PT_DEV Box set_box(const GridArgs& S) {
 template <bool FAST, int GRIDS, class PARK>
 PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const PARK& park, bool& defer) {
     if (FAST && !(ray.mint == ray.maxt)) defer = defer || !ray_guard(ray);   // a dead ray divides nothing
+    const RayRcp rr = ray_rcp<FAST>(ray);
     for (uint32_t s = 0; s < A.n_sets; ++s) {
         const GridArgs& S = A.sets[s];
         const bool live = !(ray.mint == ray.maxt);
@@ -152,15 +153,15 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const PARK& park
         ch.idx = UINT32_MAX;
         if (!GRIDS || S.n == 1u) {
             if (live) {
-                const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(ray, set_box(S));
+                const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(ray, rr, set_box(S));
                 if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, false, TRI_A10, FAST>(ray, bh, S) : trace_cell1<TRIANGLES, false, TRI_A10, FAST, false, PT_LANE_LISTS_FOR(FAST, GRIDS)>(ray, bh, S);
             }
         } else if (S.kind == KIND_TRIANGLES) {   // every lane of the wave enters: the tests of the walk are shared (pt_trace_coop.hpp)
             BoxHit bh = {};
-            if (live) bh = inter_aabb_t<FAST, true>(ray, set_box(S));
+            if (live) bh = inter_aabb_t<FAST, true>(ray, rr, set_box(S));
             ch = trace_dda_coop<COOP_CLOSEST, FAST, GRIDS == 1>(live && bh.v, ray, bh, S, defer);
         } else if (live) {
-            const BoxHit bh = inter_aabb_t<FAST, true>(ray, set_box(S));
+            const BoxHit bh = inter_aabb_t<FAST, true>(ray, rr, set_box(S));
             if (bh.v) ch = trace_dda<SPHERES, false, TRI_A10, FAST, GRIDS == 1>(ray, bh, S, defer);
         }
         if (ch.idx == UINT32_MAX) continue;
@@ -217,6 +218,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             if (FAST) defer = defer || !ray_guard(sh);
 #endif
         }
+        const RayRcp rr = ray_rcp<FAST>(sh);
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
             const bool live = path && !dark && !(sh.mint == sh.maxt);
@@ -224,7 +226,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             bool walked = false;
             if (!GRIDS || S.n == 1u) {
                 if (live) {
-                    const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(sh, set_box(S));
+                    const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(sh, rr, set_box(S));
                     if (bh.v) {
                         ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, true, TRI_A10, FAST, true>(sh, bh, S) : trace_cell1<TRIANGLES, true, TRI_A10, FAST, true, PT_LANE_LISTS_FOR(FAST, GRIDS)>(sh, bh, S);
                         walked = true;
@@ -232,11 +234,11 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
                 }
             } else if (S.kind == KIND_TRIANGLES) {
                 BoxHit bh = {};
-                if (live) bh = inter_aabb_t<FAST, true>(sh, set_box(S));
+                if (live) bh = inter_aabb_t<FAST, true>(sh, rr, set_box(S));
                 walked = live && bh.v;
                 ch = trace_dda_coop<COOP_ANY, FAST, GRIDS == 1>(walked, sh, bh, S, defer);
             } else if (live) {
-                const BoxHit bh = inter_aabb_t<FAST, true>(sh, set_box(S));
+                const BoxHit bh = inter_aabb_t<FAST, true>(sh, rr, set_box(S));
                 if (bh.v) {
                     ch = trace_dda<SPHERES, true, TRI_A10, FAST, GRIDS == 1>(sh, bh, S, defer);
                     walked = true;

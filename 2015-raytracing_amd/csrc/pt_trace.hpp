@@ -206,22 +206,32 @@ PT_DEV bool slab1_fast(float lo, float hi, float o, float d, float r, BoxHit& h,
     h.tmax = cl_min(tf, h.tmax);
     return !(h.tmin > h.tmax);
 }
-// inter_aabb (pt_device.hpp); FAST: the six slab quotients share three refined reciprocals
+// inter_aabb (pt_device.hpp); FAST: the six slab quotients share three refined reciprocals, and the boxes of all the sets a ray is tested
+// against share those: RayRcp is made once per ray (closest_all / direct_all), not once per set
+struct RayRcp { float x, y, z; };
+template <bool FAST>
+PT_DEV RayRcp ray_rcp(const Ray& r) {
+    RayRcp q;
+    q.x = q.y = q.z = 0.0f;
+    if (FAST) { q.x = rcp_refined(r.d.x); q.y = rcp_refined(r.d.y); q.z = rcp_refined(r.d.z); }
+    return q;
+}
 template <bool FAST, bool SIGNED_ZERO = true>
-PT_DEV BoxHit inter_aabb_t(const Ray& r, const Box& b) {
+PT_DEV BoxHit inter_aabb_t(const Ray& r, const RayRcp& q, const Box& b) {
     if (FAST) {
         BoxHit h;
         h.tmin = 0.0f;
         h.tmax = PT_INF;
-        const float rx = rcp_refined(r.d.x), ry = rcp_refined(r.d.y), rz = rcp_refined(r.d.z);
-        const bool okx = slab1_fast<SIGNED_ZERO>(b.lo.x, b.hi.x, r.o.x, r.d.x, rx, h, h.tfx);
-        const bool oky = slab1_fast<SIGNED_ZERO>(b.lo.y, b.hi.y, r.o.y, r.d.y, ry, h, h.tfy);
-        const bool okz = slab1_fast<SIGNED_ZERO>(b.lo.z, b.hi.z, r.o.z, r.d.z, rz, h, h.tfz);
+        const bool okx = slab1_fast<SIGNED_ZERO>(b.lo.x, b.hi.x, r.o.x, r.d.x, q.x, h, h.tfx);
+        const bool oky = slab1_fast<SIGNED_ZERO>(b.lo.y, b.hi.y, r.o.y, r.d.y, q.y, h, h.tfy);
+        const bool okz = slab1_fast<SIGNED_ZERO>(b.lo.z, b.hi.z, r.o.z, r.d.z, q.z, h, h.tfz);
         h.v = okx && oky && okz;
         return h;
     }
     return inter_aabb(r, b);
 }
+template <bool FAST, bool SIGNED_ZERO = true>
+PT_DEV BoxHit inter_aabb_t(const Ray& r, const Box& b) { return inter_aabb_t<FAST, SIGNED_ZERO>(r, ray_rcp<FAST>(r), b); }
 
 struct SphereRay { float a, inv2a; };  // ray-only part of the quadratic (A10 code.cl:203, 218)
 template <bool FAST>
