@@ -558,7 +558,10 @@ napi_value Gather(napi_env env, napi_callback_info info) {
     void* g; void* out; uint32_t n = 0, root = 0, use_rccl = 0;
     if (!get_ext(env, argv[0], &g) || napi_get_array_length(env, argv[1], &n) != napi_ok || !get_ext(env, argv[3], &out) ||
         !get_u32(env, argv[4], &root) || !get_u32(env, argv[5], &use_rccl))
-        return throw_type(env, "gather(group, [tile buffers], [tile bytes], out, root, useRccl)");
+        return throw_type(env, "gather(group, [tile buffers], [tile bytes], out, root, transport)");
+    const int gsize = mirt_group_size((mirt_group*)g);
+    if (gsize < 0) return throw_mirt(env, gsize, nullptr);
+    if ((int)n != gsize) return throw_type(env, "gather: one tile buffer per context of the group");
     std::vector<mirt_buf*> tiles(n);
     std::vector<size_t> bytes(n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -568,7 +571,7 @@ napi_value Gather(napi_env env, napi_callback_info info) {
         if (napi_get_element(env, argv[2], i, &e) != napi_ok || !get_f64(env, e, &nb) || nb < 0) return throw_type(env, "gather: tile byte counts are numbers");
         bytes[i] = (size_t)nb;
     }
-    int rc = mirt_gather((mirt_group*)g, tiles.data(), bytes.data(), (mirt_buf*)out, (int)root, (int)use_rccl);
+    int rc = mirt_gather((mirt_group*)g, tiles.data(), bytes.data(), (int)n, (mirt_buf*)out, (int)root, (int)use_rccl);
     if (rc) return throw_mirt(env, rc, mirt_group_ctx((mirt_group*)g, 0));
     return undef(env);
 }

@@ -300,6 +300,7 @@ int ensure_prepared(mirt_ctx* ctx, mirt_buf* pb, uint32_t count) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     pb->prep_sane = insane == 0;
     pb->prep_version = pb->version;
+    if (pb->prep_count != count) pb->prep_gen++;   // rebuilt in place for another count: the group spheres and the sweep array moved, a recorded graph must not replay against it
     pb->prep_count = count;
     return MIRT_OK;
 }
@@ -467,6 +468,7 @@ constexpr int kNcclUint8 = 1;   // ncclUint8 / ncclChar family: rccl.h ncclDataT
 struct mirt_group {
     std::vector<mirt_ctx*> ctxs;
     std::vector<void*> comms;    // ncclComm_t per device; empty until a gather needs RCCL
+    bool repeated_devices = false;   // rehearsal group (MIRT_GROUP_ALLOW_REPEATED_DEVICES): several contexts on one device
 };
 
 static bool live_group(const mirt_group* g) { return live_is(g, H_GROUP); }
@@ -487,10 +489,19 @@ int mirt_group_create(const int* device_ids, int n, mirt_group** out) try {
     if (!out) return fail(nullptr, MIRT_E_ARG, "mirt_group_create: null out");
     *out = nullptr;
     if (!device_ids || n < 1 || n > 64) return fail(nullptr, MIRT_E_ARG, "mirt_group_create: need 1..64 device ids");
+    // A device may appear once -- unless MIRT_GROUP_ALLOW_REPEATED_DEVICES=1 (a rehearsal switch: N contexts share the devices at hand, so
+    // the whole N-tile path -- tile arithmetic, N fused passes, the gather's offsets and orderings -- runs on a one-GPU box; such a group
+    // gathers by device copies, RCCL wants one device per rank)
+    bool repeated = false;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j)
-            if (device_ids[i] == device_ids[j]) return fail(nullptr, MIRT_E_ARG, "mirt_group_create: device %d listed twice", device_ids[i]);
+            if (device_ids[i] == device_ids[j]) repeated = true;
+    if (repeated) {
+        const char* e = getenv("MIRT_GROUP_ALLOW_REPEATED_DEVICES");
+        if (!e || atoi(e) != 1) return fail(nullptr, MIRT_E_ARG, "mirt_group_create: a device is listed twice (MIRT_GROUP_ALLOW_REPEATED_DEVICES=1 allows it for rehearsals)");
+    }
     mirt_group* g = new mirt_group();
+    g->repeated_devices = repeated;
     for (int i = 0; i < n; ++i) {
         mirt_ctx* c = nullptr;
         int rc = create_ctx(device_ids[i], &c);
@@ -531,12 +542,15 @@ void mirt_tile_rows(uint32_t height, uint32_t n_tiles, uint32_t index, uint32_t*
     if (nrows) *nrows = q + (index < r ? 1u : 0u);
 } MIRT_CATCH("mirt_tile_rows", return)
 
-int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes, mirt_buf* out, int root, int use_rccl) try {
+int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes, int n_tiles, mirt_buf* out, int root, int transport) try {
     if (!live_group(g)) return fail(nullptr, MIRT_E_HANDLE, "mirt_gather: unknown group");
     const int n = (int)g->ctxs.size();
     mirt_ctx* rc_ctx = g->ctxs[0];
-    for (auto* c : g->ctxs) FLUSH_PENDING(c);
+    // arguments first: nothing is flushed or queued on any device for a call that is going to be refused
     if (!tiles || !tile_bytes || root < 0 || root >= n) return fail(rc_ctx, MIRT_E_ARG, "mirt_gather: null argument or root out of range");
+    if (n_tiles != n) return fail(rc_ctx, MIRT_E_ARG, "mirt_gather: %d tiles for a group of %d contexts", n_tiles, n);
+    if (transport != MIRT_GATHER_AUTO && transport != MIRT_GATHER_RCCL && transport != MIRT_GATHER_COPY)
+        return fail(rc_ctx, MIRT_E_ARG, "mirt_gather: transport %d is not MIRT_GATHER_AUTO / _RCCL / _COPY", transport);
     mirt_ctx* rootc = g->ctxs[root];
     uint64_t total = 0;
     for (int i = 0; i < n; ++i) {
@@ -547,9 +561,34 @@ int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes,
     if (!live_has(out) || out->ctx != rootc) return fail(rc_ctx, MIRT_E_HANDLE, "mirt_gather: the output is not a live buffer of the root context");
     if (out->bytes < total) return fail(rc_ctx, MIRT_E_RANGE, "mirt_gather: output holds %zu bytes, the tiles add up to %llu", out->bytes, (unsigned long long)total);
     for (auto* c : g->ctxs) NOT_WHILE_CAPTURING(c, "mirt_gather");
-    if (n == 1 && !use_rccl) {   // tile == frame: one copy on the one device
+    for (auto* c : g->ctxs) FLUSH_PENDING(c);
+    // MIRT_GATHER_AUTO: RCCL when the group spans several distinct devices and librccl loads, else copies
+    bool use_rccl = transport == MIRT_GATHER_RCCL;
+    if (transport == MIRT_GATHER_AUTO && n > 1 && !g->repeated_devices) use_rccl = rccl().err.empty();
+    if (use_rccl && g->repeated_devices) return fail(rc_ctx, MIRT_E_ARG, "mirt_gather: RCCL needs one device per context (this group lists a device twice: MIRT_GATHER_COPY)");
+    if (!use_rccl) {
+        // copies queued on the root's stream, each ordered after the work queued so far on the tile's own stream: tile == frame for one
+        // context; device-to-device across contexts that share a device; hipMemcpyPeerAsync (xGMI, P2P) across devices
         HIPCHK(rootc, hipSetDevice(rootc->device));
-        if (tile_bytes[0]) HIPCHK(rootc, hipMemcpyAsync(out->ptr, tiles[0]->ptr, tile_bytes[0], hipMemcpyDeviceToDevice, rootc->stream));
+        uint64_t off = 0;
+        for (int i = 0; i < n; ++i) {
+            mirt_ctx* c = g->ctxs[i];
+            if (tile_bytes[i]) {
+                if (c->stream != rootc->stream) {
+                    hipEvent_t ev;
+                    HIPCHK(rootc, hipSetDevice(c->device));
+                    HIPCHK(rootc, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    hipError_t e = hipEventRecord(ev, c->stream);
+                    if (e == hipSuccess) { (void)hipSetDevice(rootc->device); e = hipStreamWaitEvent(rootc->stream, ev, 0); }
+                    (void)hipEventDestroy(ev);   // released once the wait has been satisfied
+                    HIPCHK(rootc, hipSetDevice(rootc->device));
+                    HIPCHK(rootc, e);
+                }
+                if (c->device == rootc->device) HIPCHK(rootc, hipMemcpyAsync((char*)out->ptr + off, tiles[i]->ptr, tile_bytes[i], hipMemcpyDeviceToDevice, rootc->stream));
+                else HIPCHK(rootc, hipMemcpyPeerAsync((char*)out->ptr + off, rootc->device, tiles[i]->ptr, c->device, tile_bytes[i], rootc->stream));
+            }
+            off += tile_bytes[i];
+        }
         out->version++;
         return MIRT_OK;
     }
@@ -562,12 +601,15 @@ int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes,
     uint64_t off = 0;
     for (int i = 0; i < n && nrc == 0; ++i) {
         if (tile_bytes[i]) {
+            (void)hipSetDevice(g->ctxs[i]->device);
             nrc = R.Send(tiles[i]->ptr, tile_bytes[i], kNcclUint8, root, g->comms[i], g->ctxs[i]->stream);
+            (void)hipSetDevice(rootc->device);
             if (nrc == 0) nrc = R.Recv((char*)out->ptr + off, tile_bytes[i], kNcclUint8, i, g->comms[root], rootc->stream);
         }
         off += tile_bytes[i];
     }
     const int erc = R.GroupEnd();
+    (void)hipSetDevice(rootc->device);
     if (nrc == 0) nrc = erc;
     if (nrc != 0) return fail(rc_ctx, MIRT_E_DEVICE, "mirt_gather: RCCL: %s", R.GetErrorString(nrc));
     out->version++;
@@ -1477,7 +1519,7 @@ int mirt_grid_build(mirt_ctx* ctx, const mirt_grid_build_desc* d, mirt_buf** cel
 } MIRT_CATCH("mirt_grid_build", return MIRT_E_DEVICE)
 
 int mirt_grid_gather_triangles(mirt_ctx* ctx, mirt_buf* order, uint32_t total, mirt_buf* pos_f64, mirt_buf* nor_f64, uint32_t nsteps,
-                               const int32_t* ops, const double* vecs, float pad_w, mirt_buf** pos_out, mirt_buf** nor_out) {
+                               const int32_t* ops, const double* vecs, float pad_w, mirt_buf** pos_out, mirt_buf** nor_out) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_grid_gather_triangles: unknown context");
     FLUSH_PENDING(ctx);
     if (!pos_out || nsteps > 4 || (nsteps && (!ops || !vecs))) return fail(ctx, MIRT_E_ARG, "mirt_grid_gather_triangles: bad argument");
@@ -1507,9 +1549,9 @@ int mirt_grid_gather_triangles(mirt_ctx* ctx, mirt_buf* order, uint32_t total, m
     HIPCHK(ctx, hipGetLastError());
     (*pos_out)->version++;
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_grid_gather_triangles", return MIRT_E_DEVICE)
 
-int mirt_mesh_ingest(mirt_ctx* ctx, const mirt_mesh_ingest_desc* d, mirt_buf* pos9_out, mirt_buf* nor9_out, mirt_buf* bounds6) {
+int mirt_mesh_ingest(mirt_ctx* ctx, const mirt_mesh_ingest_desc* d, mirt_buf* pos9_out, mirt_buf* nor9_out, mirt_buf* bounds6) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_mesh_ingest: unknown context");
     FLUSH_PENDING(ctx);
     if (!d || d->struct_size != sizeof(mirt_mesh_ingest_desc)) return fail(ctx, MIRT_E_ARG, "mirt_mesh_ingest: null descriptor or size mismatch");
@@ -1538,7 +1580,7 @@ int mirt_mesh_ingest(mirt_ctx* ctx, const mirt_mesh_ingest_desc* d, mirt_buf* po
     pos9_out->version++; nor9_out->version++; bounds6->version++;
     if (flag) return fail(ctx, MIRT_E_DATA, "mirt_mesh_ingest: an index refers past the %u vertices of the mesh", d->n_vertices);
     return MIRT_OK;
-}
+} MIRT_CATCH("mirt_mesh_ingest", return MIRT_E_DEVICE)
 
 static int check_order(mirt_ctx* ctx, mirt_buf* order, uint32_t total, uint64_t n_in) {
     if (!total) return MIRT_OK;

@@ -70,12 +70,20 @@ function buildSceneOnDevice(ctx, q, sc, p) {
     g.order.release();
   }
   d.meshes = sc.meshes.map((m, i) => {
-    const onDev = !!m.jmesh.positionsBuf;   // the soups are already on the device (queue.meshIngest = parseMeshJSON there)
-    const pos = onDev ? m.jmesh.positionsBuf : new Float64Array(m.jmesh.positions), nor = onDev ? m.jmesh.normalsBuf : new Float64Array(m.jmesh.normals);
-    const g = q.gridBuild(1, pos, b6(m.gridBounds), m.nslabs, m.jmesh.nTriangles);      // grid on the untransformed mesh (code.js:106-112)
+    // the soups are on the device already (queue.meshIngest = parseMeshJSON there) -- on the context that loaded the scene.  A row tile
+    // on ANOTHER context (renderTiled: one context per device) ingests the mesh file again on its own device: buffers do not cross contexts.
+    const jm = m.jmesh;
+    let onDev = !!jm.positionsBuf, own = false, pos, nor;
+    if (onDev && jm.positionsBuf.ctx !== ctx) {
+      const r = q.meshIngest(jm.model, scene.normalFromMat4);
+      pos = r.positionsBuf; nor = r.normalsBuf; own = true;
+    } else if (onDev) { pos = jm.positionsBuf; nor = jm.normalsBuf; }
+    else { pos = new Float64Array(jm.positions); nor = new Float64Array(jm.normals); }
+    const g = q.gridBuild(1, pos, b6(m.gridBounds), m.nslabs, jm.nTriangles);      // grid on the untransformed mesh (code.js:106-112)
     const t = q.gridGatherTriangles(g.order, g.total, pos, nor, m.steps, 0);   // normalize / scale / translate in fp64, then fp32
     g.order.release();
-    if (onDev) { pos.release(); nor.release(); m.jmesh.positionsBuf = m.jmesh.normalsBuf = null; }
+    if (own) { pos.release(); nor.release(); }
+    else if (onDev && !sc.keepSoups) { pos.release(); nor.release(); jm.positionsBuf = jm.normalsBuf = null; }
     return { prims: keep(t.pos), normals: keep(t.nor), cellOffsets: keep(g.offsets), bounds: p.meshes[i].bounds, nSlabs: m.nslabs, meshMatId: m.matId };
   });
   const mat = ctx.createBuffer(webcl.MEM_READ_ONLY, Math.max(p.materials.byteLength, 16));
@@ -92,7 +100,10 @@ class GranularRenderer {
     this.device = opt.ctx ? opt.ctx.device : pickDevice(opt.device);
     this.useGraph = !!opt.graph;
     this.ctx = opt.ctx || webcl.createContext(this.device);           // createCLBasicResources (code.js:576-608)
-    if (opt.fusion && this.ctx.setFusion) this.ctx.setFusion(2);       // ours: the runtime runs each pass of this stream as one fused launch
+    // ours: with `fusion` the runtime runs each pass of this stream as one fused launch (webcl.createContext's default); without it this
+    // renderer is the launch-by-launch path on purpose
+    if (this.ownCtx && this.ctx.setFusion) this.ctx.setFusion(opt.fusion ? 2 : 0);
+    else if (opt.fusion && this.ctx.setFusion) this.ctx.setFusion(2);
     this.q = this.ctx.createCommandQueue();
     this.program = this.ctx.createProgram(MANIFEST);
     this.program.build();
@@ -290,9 +301,13 @@ class FusedRenderer {
 function renderTiled(packed, nDevices, passes, opt) {
   opt = opt || {};
   const all = webcl.getPlatforms()[0].getDevices(webcl.DEVICE_TYPE_ALL);
-  if (all.length < nDevices) throw new Error("renderTiled: " + nDevices + " devices asked for, " + all.length + " visible");
+  // rehearsal (MIRT_GROUP_ALLOW_REPEATED_DEVICES=1, include/mirt.h): more tiles than devices -- the contexts share the devices at hand
+  const rehearse = process.env.MIRT_GROUP_ALLOW_REPEATED_DEVICES === "1";
+  if (all.length < nDevices && !rehearse) throw new Error("renderTiled: " + nDevices + " devices asked for, " + all.length + " visible");
   if (packed.rays_per_pixel === 1 && nDevices > 1) throw new Error("one ray per pixel couples the rows through seeds[col] (A10 code.cl:429): render it on one device");
-  const group = webcl.createDeviceGroup(all.slice(0, nDevices));
+  const devs = [];
+  for (let i = 0; i < nDevices; i++) devs.push(all[i % all.length]);
+  const group = webcl.createDeviceGroup(devs);
   const tiles = [];
   for (let i = 0; i < nDevices; i++) {
     const t = group.tileRows(packed.height, i);
@@ -336,6 +351,7 @@ function renderFile(file, width, height, rpp, passes, opt) {
     const q = ownCtx.createCommandQueue();
     const parseMesh = (model) => {
       const r = q.meshIngest(model, scene.normalFromMat4);
+      r.model = model;   // a row tile on another device ingests it again there (buildSceneOnDevice)
       const b = r.bounds6.map((v) => (v === Infinity ? Number.MAX_VALUE : v === -Infinity ? -Number.MAX_VALUE : v));   // an empty mesh keeps Bounds' initial values
       r.bounds = new scene.Bounds(b.slice(0, 3), b.slice(3));
       return r;
@@ -344,7 +360,11 @@ function renderFile(file, width, height, rpp, passes, opt) {
     packed = scene.packScene(sc, width, height, rpp, 1, true);
     opt = Object.assign({}, opt, { sceneObject: sc, ctx: ownCtx });
   } else packed = scene.packScene(scene.loadSceneFile(file, width, height), width, height, rpp);
-  if (opt.gpus) return renderTiled(packed, opt.gpus, passes, opt);
+  if (opt.gpus) {
+    // N contexts, one per device: each builds its own copy of the scene (the loader's soups stay on ownCtx until every tile is built)
+    if (opt.sceneObject) opt.sceneObject.keepSoups = true;
+    try { return renderTiled(packed, opt.gpus, passes, opt); } finally { if (ownCtx) ownCtx.release(); }
+  }
   const R = opt.granular ? new GranularRenderer(packed, opt) : new FusedRenderer(packed, opt);
   R.q.timerStart();
   for (let i = 0; i < passes; i++) R.executeRender(opt.bounces);

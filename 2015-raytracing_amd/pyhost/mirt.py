@@ -113,7 +113,7 @@ SYMBOLS = {
     "mirt_group_destroy": (C.c_int, [C.c_void_p]),
     "mirt_group_finish": (C.c_int, [C.c_void_p]),
     "mirt_tile_rows": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
-    "mirt_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p, C.c_int, C.c_int]),
+    "mirt_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_int, C.c_int]),
 }
 
 
@@ -480,11 +480,16 @@ class DeviceGroup:
         lib().mirt_tile_rows(height, len(self.contexts), index, C.byref(r0), C.byref(n))
         return r0.value, n.value
 
-    def gather(self, tiles, tile_bytes, out, root=0, use_rccl=False):
-        n = len(self.contexts)
+    GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2
+
+    def gather(self, tiles, tile_bytes, out, root=0, use_rccl=False, transport=None):
+        """transport: GATHER_AUTO (RCCL for N > 1 distinct devices, copies otherwise), GATHER_RCCL, GATHER_COPY; use_rccl=True == GATHER_RCCL"""
+        n = len(tiles)
         hs = (C.c_void_p * n)(*[t.h for t in tiles])
         bs = (C.c_size_t * n)(*tile_bytes)
-        rc = lib().mirt_gather(self.h, hs, bs, out.h, root, 1 if use_rccl else 0)
+        if transport is None:
+            transport = self.GATHER_RCCL if use_rccl else self.GATHER_AUTO
+        rc = lib().mirt_gather(self.h, hs, bs, n, out.h, root, transport)
         if rc != 0:
             raise MirtError(rc, lib().mirt_last_error(self.contexts[0].h).decode())
 

@@ -44,13 +44,45 @@ BYTES_PER_SAMPLE_FUSED = 24.0       # seed 4 in + 4 out, accumulator 16 out (a f
 BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0
 PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA-counted)
 PEAK_HBM_GBS = 8000.0
-# VALU wave-instructions per sample-lane (SQ_INSTS_VALU / SQ_WAVES, profiles/r2f_final) and the issue rate one SIMD sustains on
-# plain fp32 VOP2 streams at 8 waves (profiles/micro/valu_rate.hip: 2.4 nominal cycles per wave-instruction; the 2-cycle figure is the spec)
-VALU_INSTR_PER_SAMPLE = {8: 19397.0}
-SIMDS, NOMINAL_HZ, MEASURED_ISSUE_CYCLES = 1024, 2.4e9, 2.4
-# HBM bytes per k_fusedPass launch from rocprofv3 PMC passes of THIS command (profiles/r2f_final: FETCH_SIZE x 2 + WRITE_SIZE,
-# KiB -> bytes; gfx950 halves FETCH_SIZE on wide coalesced reads, MI355X_MICROARCH.md).  Valid for the default workload only.
-TRAFFIC_DEFAULT_WORKLOAD = {"fetch_bytes": 2.12e9, "write_bytes": 10.62e9, "source": "profiles/r2f_final/pmc_summary.json"}
+SIMDS, NOMINAL_HZ, MEASURED_ISSUE_CYCLES = 1024, 2.4e9, 2.4   # profiles/micro/valu_rate.hip: cycles per plain fp32 VOP2 wave-instruction at 8 waves (spec: 2)
+
+
+def csrc_sha256():
+    """Hash of the kernel sources this libmirt.so is built from: the stamp that ties a rocprofv3 PMC summary to a build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "2015-raytracing_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.cpp")) + glob.glob(os.path.join(d, "*.sh"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()
+
+
+def find_pmc_summary(path, workload_key, kernel_name):
+    """Counters for the bench line come from a FILE a rocprofv3 run wrote (profiles/run_profile.sh + summarize.py), never from constants:
+    `path` if given, else the newest profiles/*/pmc_summary.json whose stamp names THIS source tree and THIS workload.  Returns
+    (path, per-kernel counters) or (None, reason)."""
+    import glob
+    want = csrc_sha256()
+    cands = [path] if path else sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json")), key=os.path.getmtime, reverse=True)
+    why = "no profiles/*/pmc_summary.json carries a stamp for this source tree and workload"
+    for c in cands:
+        try:
+            d = json.load(open(c))
+        except (OSError, ValueError) as e:
+            why = f"{c}: {e}"
+            continue
+        st = d.get("_stamp") or {}
+        if st.get("csrc_sha256") != want or st.get("workload") != workload_key:
+            if path:
+                why = f"{c}: stamped for csrc {str(st.get('csrc_sha256'))[:12]} / {st.get('workload')}, this run is {want[:12]} / {workload_key}"
+            continue
+        k = next((v for name, v in d.items() if name.startswith(kernel_name)), None)
+        if k is None:
+            why = f"{c}: no counters for {kernel_name}"
+            continue
+        return os.path.relpath(c, ROOT), k
+    return None, why
 
 
 def cpu_baseline(packed_json, log, bounces, rpp=256):
@@ -130,6 +162,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--no-depth5", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--pmc-summary", default=None, help="pmc_summary.json of a rocprofv3 run of this command (profiles/run_profile.sh); default: the "
+                    "newest one under profiles/ stamped with this source tree and workload.  Without one, `traffic` and `issue` are null")
     args = ap.parse_args()
     if args.rpp is None:
         args.rpp = 256 if args.scene == "cornell" else 16
@@ -236,8 +270,15 @@ def main():
     kernel_name = "pt::k_fusedPass<true,1>" if has_grids else "pt::k_fusedPass<true,0>"   # <optimistic, grids: 0 none / 1 tables in LDS / 2 in memory>
     hbm_gbs = BYTES_PER_SAMPLE_FUSED * local_samples / (fused_ms * 1e-3) / 1e9
 
-    default_wl = (world == 1 and args.scene == "cornell" and (sc.width, sc.height, sc.rpp, args.bounces) == (1920, 1080, 256, 8))
-    traffic = (TRAFFIC_DEFAULT_WORKLOAD["fetch_bytes"] + TRAFFIC_DEFAULT_WORKLOAD["write_bytes"]) if default_wl else None
+    # counters: only what a named rocprofv3 summary of this build and workload holds (FETCH_SIZE / WRITE_SIZE in KiB, separate passes;
+    # gfx950 halves FETCH_SIZE on wide coalesced reads: MI355X_MICROARCH.md)
+    workload_key = f"{args.scene}_{sc.width}x{sc.height}_r{sc.rpp}_b{args.bounces}_n{world}"
+    pmc_path, pmc = find_pmc_summary(args.pmc_summary, workload_key, kernel_name) if rank == 0 else (None, "rank != 0")
+    cnt = (lambda c: pmc[c]["mean_per_dispatch"] if c in pmc else None) if pmc_path else (lambda c: None)
+    fetch, write = cnt("FETCH_SIZE"), cnt("WRITE_SIZE")
+    traffic = (fetch * 2 + write) * 1024.0 if fetch is not None and write is not None else None
+    valu, waves = cnt("SQ_INSTS_VALU"), cnt("SQ_WAVES")
+    valu_per_sample = valu / waves if valu and waves else None   # wave-instructions per wave = per sample-lane
     out = {
         "metric": "Msamples/sec (pixels x spp) at 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -247,21 +288,26 @@ def main():
                                f"{args.bounces} bounces, thin lens; fused mirt_render_pass + copyToPixel"
                                + (f"; {world} row tiles + RCCL all_gather of RGBA8" if world > 1 else ""),
                    "width": sc.width, "height": sc.height, "rays_per_pixel": sc.rpp, "bounces": args.bounces,
-                   "parallelism": f"rows/{world}"},
+                   "parallelism": f"rows/{world}", "workload_key": workload_key},
         "roofline": {"kernel": kernel_name, "bound": "valu", "achieved": round(valu_tf, 2) if flops else None, "peak": PEAK_VALU_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(valu_tf / PEAK_VALU_TFLOPS, 4) if flops else None, "traffic": traffic,
+                     "traffic_source": pmc_path if traffic is not None else None,
                      "flops_per_sample": flops, "launch_ms": round(fused_ms, 3), "resolve_ms": round(resolve_ms, 3)},
-        "issue": None if (args.bounces not in VALU_INSTR_PER_SAMPLE or args.scene != "cornell") else {
-            "what": "VALU wave-instructions issued per second by the kernel vs what 1024 SIMDs sustain on plain fp32 VOP2 streams",
-            "achieved_Ginstr_s": round(VALU_INSTR_PER_SAMPLE[args.bounces] * local_samples / 64.0 / (fused_ms * 1e-3) / 1e9, 1),
+        "issue": None if valu_per_sample is None else {
+            "what": "VALU wave-instructions issued per second by the kernel (SQ_INSTS_VALU / SQ_WAVES of the named summary x this run's samples / its launch time) "
+                    "vs what 1024 SIMDs sustain on plain fp32 VOP2 streams",
+            "valu_instr_per_sample": round(valu_per_sample, 1),
+            "achieved_Ginstr_s": round(valu_per_sample * local_samples / 64.0 / (fused_ms * 1e-3) / 1e9, 1),
             "attainable_Ginstr_s": round(SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES / 1e9, 1), "spec_Ginstr_s": round(SIMDS * NOMINAL_HZ / 2.0 / 1e9, 1),
-            "frac_of_attainable": round(VALU_INSTR_PER_SAMPLE[args.bounces] * local_samples / 64.0 / (fused_ms * 1e-3) / (SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES), 4),
-            "source": "profiles/r2f_final/pmc_summary.json, profiles/micro/README.md"},
+            "frac_of_attainable": round(valu_per_sample * local_samples / 64.0 / (fused_ms * 1e-3) / (SIMDS * NOMINAL_HZ / MEASURED_ISSUE_CYCLES), 4),
+            "source": pmc_path + ", profiles/micro/README.md"},
         "roofline_hbm": {"kernel": kernel_name, "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
-                         "traffic_note": ("algorithmic 12.7 GB/launch (seeds in + out, accumulator out); measured 2.12 + 10.62 GB (FETCH_SIZE x2 + WRITE_SIZE, "
-                                          "separate PMC passes): no re-reads, no scratch") if default_wl else None,
+                         "traffic_note": (f"algorithmic {BYTES_PER_SAMPLE_FUSED * local_samples / 1e9:.2f} GB/launch (seeds in + out, accumulator out); measured "
+                                          f"{fetch * 2 * 1024 / 1e9:.2f} + {write * 1024 / 1e9:.2f} GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, {pmc_path})") if traffic is not None
+                                         else f"no counters: {pmc if not pmc_path else 'summary lacks FETCH_SIZE / WRITE_SIZE'}",
                          "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
+        "build": {"csrc_sha256": csrc_sha256()[:16]},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(packed, log, args.bounces, sc.rpp)

@@ -207,8 +207,10 @@ MIRT_API int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on);
  *     mirt_buf_device_ptr drains whatever is held.
  *   - errors of a held enqueue (a buffer too small, a grid failing validation) are reported by the call that flushes it, and the
  *     held enqueues after the failing one are dropped (at level 0 the host would have stopped at that enqueue's exception).
- * Level 0 (default): every enqueue launches its kernel.  The environment variable MIRT_FUSION=2 sets the level of every new
- * context.  mirt_ctx_fused_passes: how many passes of this context ran fused. */
+ * Level 0 (the default of mirt_ctx_create): every enqueue launches its kernel.  The environment variable MIRT_FUSION=0|2 sets the level
+ * of every new context.  The WebCL object model above this ABI (host/webcl.js webcl.createContext) asks for level 2 itself unless the
+ * variable is set: its one client, the reference page, cannot observe the difference.
+ * mirt_ctx_fused_passes: how many passes of this context ran fused. */
 MIRT_API int mirt_ctx_set_fusion(mirt_ctx* ctx, int level);
 MIRT_API int mirt_ctx_fused_passes(mirt_ctx* ctx, uint64_t* count);
 
@@ -296,9 +298,13 @@ MIRT_API int mirt_graph_release(mirt_graph* graph);
  * The reference is a single-device page (one context, one queue: A10 code.js:582, 592).  Every ray is independent, so a frame
  * shards by pixel rows; ray ids stay global (mirt_pass_desc.row0 / nrows), which makes the frame independent of the tiling.
  * A group is N contexts, one per device, driven from the one host thread: enqueue the tile passes on each context (launches are
- * asynchronous), then mirt_gather assembles the tiles' buffers on the root device -- RCCL (ncclCommInitAll + one grouped
- * ncclSend / ncclRecv exchange: N - 1 peers, N - 1 distinct xGMI links into the root) for N > 1, a device copy for N == 1
- * (`use_rccl` != 0 forces the RCCL path even then, so a one-GPU box exercises it).  librccl is loaded on first use. */
+ * asynchronous), then mirt_gather assembles the tiles' buffers on the root device.  Transports: RCCL (ncclCommInitAll + one grouped
+ * ncclSend / ncclRecv exchange: N - 1 peers, N - 1 distinct xGMI links into the root; librccl is loaded on first use), or plain copies
+ * queued on the root's stream (hipMemcpyPeerAsync across devices, a device copy inside one), each ordered after the tile's own stream.
+ * MIRT_GATHER_AUTO picks RCCL for N > 1 distinct devices when librccl loads, copies otherwise; _RCCL / _COPY force one (a one-GPU box
+ * exercises the RCCL calls with a one-rank communicator).
+ * Rehearsal switch: with MIRT_GROUP_ALLOW_REPEATED_DEVICES=1 in the environment mirt_group_create accepts a device listed several
+ * times -- N contexts on the devices at hand, so the whole N-tile path runs on a one-GPU box; such a group gathers by copies only. */
 typedef struct mirt_group mirt_group;
 MIRT_API int mirt_group_create(const int* device_ids, int n, mirt_group** out);
 MIRT_API int mirt_group_size(const mirt_group* g);
@@ -307,9 +313,10 @@ MIRT_API int mirt_group_destroy(mirt_group* g);                       /* destroy
 MIRT_API int mirt_group_finish(mirt_group* g);                        /* queue.finish() on every device */
 /* contiguous row tiles whose sizes differ by at most one row (the first height % n_tiles tiles take the extra one) */
 MIRT_API void mirt_tile_rows(uint32_t height, uint32_t n_tiles, uint32_t index, uint32_t* row0, uint32_t* nrows);
-/* out[sum of tile_bytes[0..i-1] ...] = the first tile_bytes[i] bytes of tiles[i] (a buffer of context i), for every i;
- * `out` is a buffer of context `root`.  Ordered after the work queued on each context; complete after mirt_finish(root ctx). */
-MIRT_API int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes, mirt_buf* out, int root, int use_rccl);
+/* out[sum of tile_bytes[0..i-1] ...] = the first tile_bytes[i] bytes of tiles[i] (a buffer of context i), for every i < n_tiles
+ * (n_tiles must equal mirt_group_size); `out` is a buffer of context `root`.  Ordered after the work queued on each context; complete after mirt_finish(root ctx). */
+enum { MIRT_GATHER_AUTO = 0, MIRT_GATHER_RCCL = 1, MIRT_GATHER_COPY = 2 };
+MIRT_API int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes, int n_tiles, mirt_buf* out, int root, int transport);
 
 /* ---- measurement: HIP events on the context's stream ---------------------------------- */
 MIRT_API int mirt_timer_start(mirt_ctx* ctx);

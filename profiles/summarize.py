@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/summarize.py <gpurun_out/prof_TAG> <profiles/DIR> -- condense one run_profile.sh output into
-kernel_stats.csv + pmc_summary.json (mean per dispatch, per kernel, per counter) and print the fused kernel's line."""
+"""profiles/summarize.py <gpurun_out/prof_TAG> <profiles/DIR> [workload_key] -- condense one run_profile.sh output into
+kernel_stats.csv + pmc_summary.json (mean per dispatch, per kernel, per counter) and print the fused kernel's line.
+The summary is STAMPED with the hash of the kernel sources it was measured on and the workload (run_profile.sh records both on
+the GPU box, in stamp.json): bench.py only quotes counters from a summary whose stamp matches the build it is running."""
 import collections, csv, glob, json, os, shutil, sys
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -17,8 +19,15 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mix", "pmc_sq3", "
         out.setdefault(r["Kernel_Name"].split("(")[0], {})["VGPR_Count"] = int(r["VGPR_Count"])
     for k, v in agg.items():
         out.setdefault(k, {}).update({c: {"mean_per_dispatch": sum(x) / len(x), "dispatches": len(x)} for c, x in v.items()})
+stamp = os.path.join(src, "stamp.json")
+if os.path.exists(stamp):
+    out["_stamp"] = json.load(open(stamp))
+    if len(sys.argv) > 3:
+        out["_stamp"]["workload"] = sys.argv[3]
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 f = next((v for k, v in out.items() if "k_fusedPass<true" in k), out.get("pt::k_fusedPass", {}))
+if "_stamp" in out:
+    print("stamp:", out["_stamp"])
 g = lambda c: f.get(c, {}).get("mean_per_dispatch", float("nan"))
 waves = g("SQ_WAVES")
 print(open(os.path.join(dst, "kernel_stats.csv")).read().split("\n")[1])

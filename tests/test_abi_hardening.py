@@ -16,9 +16,9 @@ def M(pkg):
     return mirt
 
 
-def code(fn, *a):
+def code(fn, *a, **kw):
     with pytest.raises(Exception) as e:
-        fn(*a)
+        fn(*a, **kw)
     return e.value.code
 
 
@@ -114,8 +114,8 @@ def test_grid_build_counts_slots_in_64_bits(M):
 
 @pytest.mark.parametrize("use_rccl", [False, True])
 def test_device_group_renders_row_tiles_and_gathers(M, pkg, use_rccl):
-    """mirt_group over the one device this box has: two row tiles rendered on its context, gathered into one frame (device copy, and
-    through RCCL with a one-rank communicator: ncclSend / ncclRecv to self inside one group) == the whole frame rendered at once."""
+    """mirt_group over the one device this box has, one context: its tile is the frame; gathered by the device copy and through RCCL with a
+    one-rank communicator (ncclSend / ncclRecv to self inside one group) == the compiled reference's frame.  N > 1: the next test."""
     import a10_pass as A
     from conftest import load_fixture
     from raytracing_amd.pyhost import render
@@ -142,3 +142,41 @@ def test_device_group_renders_row_tiles_and_gathers(M, pkg, use_rccl):
     fr.release()
     grp.destroy()
     assert M.lib().mirt_finish(ctx.h) == E_HANDLE      # the group took its contexts with it
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 8])
+def test_device_group_n_contexts_render_tiles_and_gather(M, pkg, n, monkeypatch):
+    """The C-ABI N-device path with N > 1 on the one GPU reachable here (the rehearsal switch of include/mirt.h): N contexts on device 0,
+    each renders ITS mirt_tile_rows tile of cornell_teapot3 (grid meshes, two lights; 24 rows over 5 tiles = uneven heights) with global
+    ray ids, mirt_gather assembles the RGBA8 and the radiance tiles at their offsets by copies ordered after each context's own stream:
+    frame and radiance == the compiled reference's.  Everything of the N > 1 path except the transport over xGMI."""
+    import a10_pass as A
+    from conftest import load_fixture
+    from raytracing_amd.pyhost import render
+    fx, sc = load_fixture("cornell_teapot3_32x24_r4")
+    assert code(M.DeviceGroup, [0] * n) == E_ARG            # a device listed twice is refused ...
+    monkeypatch.setenv("MIRT_GROUP_ALLOW_REPEATED_DEVICES", "1")   # ... unless the rehearsal switch is on
+    grp = M.DeviceGroup([0] * n)
+    seeds = fx["seeds_in"]
+    frs, acc = [], 0
+    for i, ctx in enumerate(grp.contexts):
+        row0, nrows = grp.tile_rows(sc.height, i)
+        assert row0 == acc and nrows in (sc.height // n, sc.height // n + 1)
+        acc += nrows
+        fr = render.FusedRenderer(ctx, sc, seeds=seeds, row0=row0, nrows=nrows, want_radiance=True)
+        fr.execute_render()                                  # asynchronous: the N passes are queued on N streams
+        frs.append(fr)
+    assert acc == sc.height
+    root = grp.contexts[0]
+    npix = sc.width * sc.height
+    frame, rad = root.buffer(npix * 4), root.buffer(npix * 16)
+    assert code(grp.gather, [f.pixel for f in frs], [f.npix * 4 for f in frs], frame, transport=M.DeviceGroup.GATHER_RCCL) == E_ARG   # one device per rank
+    assert code(grp.gather, [f.pixel for f in frs][:-1], [f.npix * 4 for f in frs][:-1], frame) == E_ARG                               # one tile per context
+    grp.gather([f.pixel for f in frs], [f.npix * 4 for f in frs], frame)
+    grp.gather([f.radiance for f in frs], [f.npix * 16 for f in frs], rad, transport=M.DeviceGroup.GATHER_COPY)
+    grp.finish()
+    assert np.array_equal(frame.read(np.uint8).reshape(-1, 4), fx["pixel"])
+    assert np.array_equal(rad.read(np.float32).view(np.uint32).reshape(-1, 4), fx["radiance"].view(np.uint32).reshape(-1, 4))
+    for f in frs:
+        f.release()
+    grp.destroy()

@@ -201,9 +201,11 @@ def test_our_renderer_issues_the_same_launches_as_the_reference_host(name):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_replayed_reference_host_stream_matches_compiled_reference(name, tmp_path):
     """The reference host's recorded call stream, replayed call for call through webcl.js -> mirt.node -> libmirt.so -> HIP:
-    every frame it reads back, its accumulator and its seed buffer == the compiled reference kernels run on the same stream."""
+    every frame it reads back, its accumulator and its seed buffer == the compiled reference kernels run on the same stream.
+    MIRT_FUSION=0: every enqueue launches (webcl.createContext fuses whole passes by default: tests/test_fusion.py runs that)."""
     out = str(tmp_path / "r")
-    rep = json.loads(run_node(os.path.join(HOST, "replay.js"), CT.golden_prefix(name), out))
+    rep = json.loads(run_node(os.path.join(HOST, "replay.js"), CT.golden_prefix(name), out, env=dict(os.environ, MIRT_FUSION="0")))
+    assert rep["fusedPasses"] == 0, rep
     assert rep["leaked"] == 1 and rep["checked"]["structSizes"] == 3, rep   # the page script never releases its bouncePaths kernel
     ex = np.load(CT.golden_prefix(name) + "_expect.npz")
     raw = open(out + ".reads.bin", "rb").read()

@@ -33,10 +33,13 @@ def ctx(pkg):
 @pytest.mark.skipif(node is None, reason="node is not installed")
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_reference_host_stream_fused_matches_compiled_reference(name, tmp_path):
-    """tests/test_calltrace.py's GPU test with MIRT_FUSION=2 in the environment -- the switch for a page that cannot be edited: the
-    reference host's unmodified stream, every pass of it fused, reads back the compiled reference's bytes."""
+    """tests/test_calltrace.py's GPU test at webcl.createContext's DEFAULT (fusion level 2; MIRT_FUSION in the environment is the switch
+    for a page that cannot be edited, either way): the reference host's unmodified stream, every pass of it fused, reads back the compiled
+    reference's bytes."""
     out = str(tmp_path / "r")
-    rep = json.loads(run_node(os.path.join(HOST, "replay.js"), CT.golden_prefix(name), out, env=dict(os.environ, MIRT_FUSION="2")))
+    env = dict(os.environ)
+    env.pop("MIRT_FUSION", None)   # nothing in the environment: webcl.createContext's own default (level 2) is what is tested
+    rep = json.loads(run_node(os.path.join(HOST, "replay.js"), CT.golden_prefix(name), out, env=env))
     assert rep["fusedPasses"] == CASES[name][4], rep
     ex = np.load(CT.golden_prefix(name) + "_expect.npz")
     raw = open(out + ".reads.bin", "rb").read()

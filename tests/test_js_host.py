@@ -213,6 +213,21 @@ def test_node_device_group_render(tmp_path, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["--gpus", "2"], ["--gpus", "8"], ["--gpus", "3", "--device-grid"], ["--gpus", "1", "--device-grid"]])
+def test_node_device_group_render_n_tiles(tmp_path, flags):
+    """`render --gpus N` with N > 1 on the one GPU of the box (MIRT_GROUP_ALLOW_REPEATED_DEVICES=1: the N contexts of the group share
+    device 0): N fused renderers on N row tiles (36 rows over 8 = uneven), group.gather of the RGBA8 and radiance tiles on context 0,
+    one read-back == the compiled reference's frame.  With --device-grid every tile's context ingests the mesh files and bins them on
+    the device itself (buffers do not cross contexts; the loader's context is released when the tiles are built)."""
+    fx, sc = load_fixture("own_gems_48x36_r4")
+    out = str(tmp_path / "frame.rgba")
+    run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "gems.xml"), "48", "36", "4", "1", out, *flags,
+             env=dict(os.environ, MIRT_GROUP_ALLOW_REPEATED_DEVICES="1"))
+    assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), fx["pixel"])
+    assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(fx["radiance"]))
+
+
+@pytest.mark.gpu
 def test_node_progressive_passes_and_explicit_seeds(tmp_path):
     """three passes with host-supplied seeds (the reference uploads a seed array, A10 code.js:1140-1154) == oracle."""
     import a10_pass as A
