@@ -198,10 +198,13 @@ class PassState:
         return {k: getattr(self, k).copy() for k in names}
 
 
-def run_pass(k, sc, st, bounces=5, checkpoints=None, init_acu=True):
+def run_pass(k, sc, st, bounces=5, checkpoints=None, init_acu=True, rows=None):
     """One executeRender() (code.js:1806-1854).  `checkpoints`: optional dict that
-    receives snapshots after the primary segment ('primary') and each bounce."""
-    n = sc.total_rays
+    receives snapshots after the primary segment ('primary') and each bounce.
+    `rows`: launch the 2-D initTrace over the first `rows` image rows only and every 1-D kernel over their rays -- the camera still
+    says sc.height rows, so these ARE rays 0 .. width*rows*rpp-1 of the full frame (a top band of a frame too big to hold whole)."""
+    h = sc.height if rows is None else rows
+    n = sc.width * h * sc.rpp
     g1 = _ceil(n, WAVE)
     B = k.buf          # host pointer (CPU kernels) or device mirror (oracle/ref_gpu.py)
     if init_acu:  # preRender -> prepareInitAcu (code.js:1078-1099), once per render
@@ -211,7 +214,7 @@ def run_pass(k, sc, st, bounces=5, checkpoints=None, init_acu=True):
     cp, _c = _f(sc.cam)
     # getLocalWS(2, ...) with a multiple of 64 -> [8, 8]  (code.js:661-663)
     k.initTrace(B(st.seeds), B(st.rays), B(st.pois), bp, cp, sc.focal_length, sc.lens_rad, sc.rpp,
-                _ceil(sc.width, 8), _ceil(sc.height, 8))
+                _ceil(sc.width, 8), _ceil(h, 8))
 
     def closest():
         if sc.has_spheres:
@@ -256,7 +259,7 @@ def run_pass(k, sc, st, bounces=5, checkpoints=None, init_acu=True):
             k.flush()
             checkpoints["bounce1"] = st.snapshot()
     m = np.float32(1.0 / (sc.rpp * st.passes))  # code.js:1412: double division, narrowed by Float32Array
-    k.copyToPixel(B(st.pixel), B(st.acu), float(m), sc.width * sc.height, sc.rpp, _ceil(sc.width * sc.height, WAVE))
+    k.copyToPixel(B(st.pixel), B(st.acu), float(m), sc.width * h, sc.rpp, _ceil(sc.width * h, WAVE))
     st.passes += 1
     k.flush()
     return st

@@ -52,6 +52,9 @@ CASES = [
     ("cornell_official_64x48_r1", "cornell_official.xml", 64, 48, 1, True),  # dropped-on-max-face triangles
     ("twoLights_32x24_r4", "twoLights.xml", 32, 24, 4, True),
     ("threeLights_32x24_r1", "threeLights.xml", 32, 24, 1, True),
+    ("basic2_32x24_r4", "basic2.xml", 32, 24, 4, True),                    # the remaining three of the reference's ten A10 scenes
+    ("cornell_teapot_32x24_r4", "cornell_teapot.xml", 32, 24, 4, True),
+    ("cornell_teapot2_32x24_r4", "cornell_teapot2.xml", 32, 24, 4, True),
     ("cornell_320x240_r16", "cornell.xml", 320, 240, 16, False),
     # our own scenes (tests/scenes/page): inputs packed by the REFERENCE host code, outputs by the reference kernels
     ("own_studio_48x36_r4", "@studio.xml", 48, 36, 4, True),

@@ -30,6 +30,9 @@ CASES = [
     ("frame_a07_teapot_n2_160x120", 7, "teapot.json", 160, 120, 2, False),   # n_slabs 2 = the page's default
     ("frame_a07_teapot_n8_160x120", 7, "teapot.json", 160, 120, 8, False),
     ("frame_a07_parliament_n16_160x120", 7, "house_of_parliament.json", 160, 120, 16, False),   # config 3's mesh
+    ("frame_a04_house_160x120", 4, "house.json", 160, 120, 0, False),        # the third selectable mesh of the A04 / A07 pages
+    ("frame_a07_house_n2_160x120", 7, "house.json", 160, 120, 2, False),
+    ("frame_a07_house_n8_160x120", 7, "house.json", 160, 120, 8, False),
     ("frame_a07_mol_benzene_n2_96x64", 7, "benzene.pdb", 96, 64, 2, False),      # molecule mode, the page's default n_slabs
     ("frame_a07_mol_c60_n4_160x120", 7, "c60.pdb", 160, 120, 4, False),
     ("frame_a07_mol_dna_n8_160x120", 7, "dna.pdb", 160, 120, 8, False),

@@ -16,6 +16,7 @@ FULL_CASES = [
     "cornell_64x48_r1", "cornell_32x24_r4", "cornell_16x12_r9",
     "cornell_teapot3_64x48_r1", "cornell_teapot3_32x24_r4", "cornell_official_64x48_r1",
     "twoLights_32x24_r4", "threeLights_32x24_r1",
+    "basic2_32x24_r4", "cornell_teapot_32x24_r4", "cornell_teapot2_32x24_r4",   # with these, all ten of the reference's A10 scenes
     "own_studio_48x36_r4", "own_gems_48x36_r4", "own_gems_64x48_r1", "own_flat_32x24_r4",
 ]
 OWN_SCENES = {"own_studio_48x36_r4": ("studio.xml", 48, 36, 4), "own_gems_48x36_r4": ("gems.xml", 48, 36, 4),

@@ -199,7 +199,8 @@ def _full_size(ctx, name, size):
 @pytest.mark.parametrize("name,size", [("frame_a01_512x512", None), ("frame_a04_parliament_96x64", (1024, 1024)), ("frame_a04_teapot_160x120", (1024, 1024)),
                                        ("frame_a07_parliament_n16_160x120", (1920, 1080)), ("frame_a07_teapot_n2_160x120", (1920, 1080)),
                                        ("frame_a07_mol_3IZ4_n16_96x64", (1920, 1080)), ("frame_a07_mol_c60_n4_160x120", (1920, 1080)),
-                                       ("frame_a07_own_terrain_n5_96x64", (1920, 1080))])
+                                       ("frame_a07_own_terrain_n5_96x64", (1920, 1080)),
+                                       ("frame_a04_house_160x120", (1024, 1024)), ("frame_a07_house_n2_160x120", (1920, 1080)), ("frame_a07_house_n8_160x120", (1920, 1080))])
 def test_full_size_frames_equal_the_reference_binaries(ctx, pkg, name, size):
     """BASELINE configs 1-3 (and the molecule mode) at full size against the REFERENCE'S OWN kernels: Assign01 / 04 / 07 code.cl as AMD's
     OpenCL toolchain builds them for gfx950, run on the device (oracle/frame_pass.run_frame_gpu): every pixel, and every ray's maxt."""

@@ -2,6 +2,7 @@
 compiled reference kernels and (b) the CPU oracle on the same seeded inputs.  Bit-exact: integer hit
 ids (matId), seeds, every fp32 buffer.  Both kernel families are covered: the fourteen reference-shaped
 kernels enqueued in executeRender's order, and the fused one-launch pass."""
+import ctypes as C
 import hashlib
 
 import numpy as np
@@ -249,7 +250,8 @@ def test_degenerate_scenes_match_oracle(ctx, pkg, case):
 
 
 MEDIUM = ["basic_32x24_r4", "cornell_32x24_r4", "triangles_32x24_r4", "twoLights_32x24_r4", "threeLights_32x24_r1", "cornell_official_64x48_r1",
-          "cornell_teapot3_32x24_r4", "own_flat_32x24_r4", "own_gems_48x36_r4", "own_studio_48x36_r4"]
+          "cornell_teapot3_32x24_r4", "own_flat_32x24_r4", "own_gems_48x36_r4", "own_studio_48x36_r4",
+          "basic2_32x24_r4", "cornell_teapot_32x24_r4", "cornell_teapot2_32x24_r4"]
 
 
 @pytest.mark.parametrize("name", MEDIUM)
@@ -545,6 +547,57 @@ def test_config5_tile_at_full_scale(ctx, pkg):
         outs.append(t.pixel.read(np.uint8))
         t.release()
     assert np.array_equal(outs[0], outs[1]) and outs[0].reshape(-1, 4)[:, :3].max() > 0
+
+
+def test_config5_one_gpus_share_at_full_size(ctx, pkg):
+    """BASELINE config 5 as ONE of its eight GPUs sees it: the 270-row tile of 3840x2160 x 1024 rays per pixel, thin lens on --
+    1 061 683 200 samples, 4.2 GB of seeds + 17 GB of accumulators resident -- rendered whole, through mirt_tile_rows' arithmetic.
+    Tile 0 (rows 0..269) and tile 4 (rows 1080..1349, the image centre, ray ids beyond 2^32): each deterministic, a 48-row band cut
+    out of it equal to that band rendered alone, integer sample counts in acu.w.  Times land in gpurun_out/config5_share.json.
+    (The 32 x 32 lens grid itself is pinned against the reference binary in tests/test_ref_gpu.py.)"""
+    import json
+    import os
+    from conftest import ROOT
+    from raytracing_amd.pyhost import mirt, render, scene
+    sc = scene.PackedScene(open(os.path.join(ROOT, "tests", "golden", "scene_cornell_3840x2160_r1024.json")).read())
+    assert (sc.width, sc.height, sc.rpp) == (3840, 2160, 1024)
+    ctx.set_profiling(True)
+    report = {}
+    for tile in (0, 4):
+        r0, nr = C.c_uint32(), C.c_uint32()
+        mirt.lib().mirt_tile_rows(sc.height, 8, tile, C.byref(r0), C.byref(nr))
+        row0, nrows = r0.value, nr.value
+        assert nrows == 270 and row0 == 270 * tile
+        fr = render.FusedRenderer(ctx, sc, row0=row0, nrows=nrows, want_radiance=False)
+        assert fr.nrays == 3840 * 270 * 1024
+        fr.execute_render(bounces=5, fresh=True)
+        ms5 = ctx.pass_timing()[0]
+        pix = fr.pixel.read(np.uint8).reshape(nrows, sc.width, 4)
+        for off in (0, 2 * fr.nrays, 4 * fr.nrays - (1 << 26)):            # three 256 MB windows of the 17 GB accumulator
+            a = fr.acu.read(np.float32, count=1 << 26, offset=4 * off).reshape(-1, 4)
+            assert np.array_equal(a[:, 3], np.round(a[:, 3])) and a[:, 3].min() >= 0 and a[:, 3].max() <= 7
+            assert np.isfinite(a).all() and (a[:, :3] >= 0).all()
+        ctx.seed_fill(fr.seeds, fr.first_ray, fr.nrays, 0)
+        fr.passes = 1
+        fr.execute_render(bounces=5, fresh=True)                            # again from the same seeds: the same frame
+        assert np.array_equal(fr.pixel.read(np.uint8).reshape(nrows, sc.width, 4), pix)
+        ctx.seed_fill(fr.seeds, fr.first_ray, fr.nrays, 0)
+        fr.passes = 1
+        fr.execute_render(bounces=8, fresh=True)
+        ms8 = ctx.pass_timing()[0]
+        fr.release()
+        band = render.FusedRenderer(ctx, sc, row0=row0 + 100, nrows=48, want_radiance=False)
+        band.execute_render(bounces=5, fresh=True)
+        assert np.array_equal(band.pixel.read(np.uint8).reshape(48, sc.width, 4), pix[100:148])
+        band.release()
+        assert pix[..., :3].max() > 0
+        report[f"tile{tile}"] = {"row0": row0, "nrows": nrows, "samples": 3840 * 270 * 1024, "ms_5_bounces": round(ms5, 2), "ms_8_bounces": round(ms8, 2),
+                                 "Msamples_s_5": round(3840 * 270 * 1024 / ms5 / 1e3, 1), "Msamples_s_8": round(3840 * 270 * 1024 / ms8 / 1e3, 1)}
+    ctx.set_profiling(False)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(report, open(os.path.join(out, "config5_share.json"), "w"), indent=1)
+    print("config5 share:", report)
 
 
 def test_error_paths(ctx, pkg):

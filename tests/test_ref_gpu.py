@@ -158,7 +158,8 @@ def test_reference_binary_on_the_device_equals_the_fixtures(name):
 @pytest.mark.gpu
 @needs_gpu_ref
 @pytest.mark.parametrize("name", ["basic_32x24_r4", "cornell_32x24_r4", "triangles_32x24_r4", "twoLights_32x24_r4", "threeLights_32x24_r1",
-                                  "cornell_official_64x48_r1", "cornell_teapot3_32x24_r4", "own_flat_32x24_r4", "own_gems_48x36_r4", "own_studio_48x36_r4"])
+                                  "cornell_official_64x48_r1", "cornell_teapot3_32x24_r4", "own_flat_32x24_r4", "own_gems_48x36_r4", "own_studio_48x36_r4",
+                                  "basic2_32x24_r4", "cornell_teapot_32x24_r4", "cornell_teapot2_32x24_r4"])
 def test_every_scene_equals_the_reference_binary_at_depth_8(pkg, name):
     """Every scene the fixtures carry (the reference's A10 scenes incl. the grid-mesh ones, and ours) at 480x270 x 16 rays per pixel,
     depth 8, two progressive passes (2.07 M samples each): mirt_render_pass against the reference binary on the device, same seeds --
@@ -223,6 +224,52 @@ def test_headline_frame_equals_the_reference_binary(pkg):
             G.chk(G.hip().hipMemcpy(want.ctypes.data_as(C.c_void_p), C.c_void_p(st.acu.ptr + 4 * off), 4 * m, 2), "D2H")
             got = fr.acu.read(np.float32, count=m, offset=4 * off)
             assert np.array_equal(canon(got), canon(want)), f"accumulators differ in floats [{off}, {off + m})"
+    finally:
+        for b in (st.rays, st.pois, st.shadow, st.acu, st.seeds, st.pixel):
+            b.free()
+        k.release()
+        fr.release()
+        ctx.destroy()
+
+
+@pytest.mark.gpu
+@needs_gpu_ref
+@pytest.mark.parametrize("bounces", [5, 8])
+def test_config5_lens_grid_band_equals_the_reference_binary(pkg, bounces):
+    """BASELINE config 5's lens grid -- 3840x2160, 1024 rays per pixel = the 32 x 32 stratified thin-lens grid of initTrace
+    (code.cl:482-509) -- pinned against the reference itself: its 2-D initTrace launched over global [3840, 8] (the first eight rows:
+    31 457 280 rays, whose ids are exactly those of our row tile row0 = 0, nrows = 8; the camera still says 2160 rows) and its 1-D
+    kernels over those rays, on the MI355X, against mirt_render_pass on the tile: every accumulator, seed and pixel.  (Below row 1092 the
+    reference's own 32-bit `(cols*row+col)*rays_per_pixel` wraps: the top band is where "the reference's output" exists at this size.)"""
+    from raytracing_amd.pyhost import mirt, render, scene
+    base = scene.PackedScene(open(os.path.join(ROOT, "tests", "golden", "scene_cornell_3840x2160_r1024.json")).read())
+    sc = A.Scene(base.d)
+    assert (sc.width, sc.height, sc.rpp) == (3840, 2160, 1024) and sc.lens_rad > 0
+    rows = 8
+    n, npix = sc.width * rows * sc.rpp, sc.width * rows
+    ctx = mirt.Context(0)
+    fr = render.FusedRenderer(ctx, base, row0=0, nrows=rows, want_radiance=False)   # seeds generated on the device, global ids
+    seeds = fr.seeds.read(np.int32)
+    assert seeds.size == n
+    fr.execute_render(bounces=bounces, fresh=True)
+    ctx.finish()
+    k = G.GpuRefKernels()
+
+    class St:
+        pass
+    st = St()
+    st.rays, st.pois, st.shadow = G.DevBuf(n * 48), G.DevBuf(n * 64), G.DevBuf(n * 48)
+    st.acu, st.seeds, st.pixel = G.DevBuf(n * 16), G.DevBuf(n * 4), G.DevBuf(npix * 4)
+    st.passes = 1
+    st.seeds.upload(seeds)
+    del seeds
+    A.run_pass(k, sc, st, bounces=bounces, rows=rows)
+    try:
+        pix = fr.pixel.read(np.uint8)
+        assert pix.reshape(-1, 4)[:, :3].max() > 0
+        assert np.array_equal(st.pixel.download(np.uint8, npix * 4), pix), "pixels"
+        assert np.array_equal(st.seeds.download(np.int32, n), fr.seeds.read(np.int32)), "seeds"
+        assert np.array_equal(canon(st.acu.download(np.float32, 4 * n)), canon(fr.acu.read(np.float32))), "accumulators"
     finally:
         for b in (st.rays, st.pois, st.shadow, st.acu, st.seeds, st.pixel):
             b.free()
