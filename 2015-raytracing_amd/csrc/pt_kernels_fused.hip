@@ -36,7 +36,7 @@
 #define PT_LANE_LISTS 1          // optimistic kernel: single-cell triangle sets through per-lane candidate lists (pt_trace.hpp trace_cell1, LANES)
 #endif
 #ifndef PT_LANE_LISTS_GRIDS
-#define PT_LANE_LISTS_GRIDS 0    // ... in the grid kernels as well
+#define PT_LANE_LISTS_GRIDS 1    // ... in the grid kernels as well (cornell_teapot3 35.8 -> 33.4 ms, cornell_teapot 24.0 -> 22.7, own_gems 12.4 -> 12.8)
 #endif
 #define PT_LANE_LISTS_FOR(FAST, GRIDS) ((FAST) && PT_LANE_LISTS && ((GRIDS) == 0 || PT_LANE_LISTS_GRIDS))
 

@@ -68,7 +68,9 @@ PT_DEV float sqrt_core(float x) {
     return r;
 }
 PT_DEV float cl_sqrt(float x) {
-#if PT_EXACT_FAST_SQRT
+#if PT_PLAIN_DIV
+    return __builtin_sqrtf(x);
+#elif PT_EXACT_FAST_SQRT
     float r = sqrt_core(x);
     // 0 < |x| < 2^-96 (hipcc's own scaling threshold), as ONE unsigned compare on the bits of |x|: zero wraps to the top, NaN / inf sit above
     if (__builtin_expect((__float_as_uint(x) & 0x7FFFFFFFu) - 1u < 0x0F800000u - 1u, 0)) r = __builtin_sqrtf(x);   // rare lanes only
@@ -105,7 +107,15 @@ PT_DEV uint32_t f2u(float f) {
 //      |n| in [2^-60, 2^60] (2^38 random pairs + every mantissa of d, zero mismatches); for n = +-0 the un-refined
 //      product n*r already is the quotient (sign included) and is what div_exact3 returns.
 // Outside those windows the affected lanes (and only they) redo the operation with the compiler's division.
+#ifndef PT_PLAIN_DIV
+#define PT_PLAIN_DIV 0   // 1 (with -fno-hip-fp32-correctly-rounded-divide-sqrt): every division and sqrt of the optimistic kernel as the compiler's
+                         // 2.5-ulp forms -- the arithmetic of the reference built WITHOUT -cl-fp32-correctly-rounded-divide-sqrt.  A timing
+                         // experiment only: no reference exists for its bits
+#endif
 PT_DEV float rcp_refined(float d) {
+#if PT_PLAIN_DIV
+    return 1.0f / d;
+#endif
     float r = __builtin_amdgcn_rcpf(d);
     float e = __builtin_fmaf(-d, r, 1.0f);
     return __builtin_fmaf(e, r, r);
@@ -118,6 +128,9 @@ PT_DEV float div_shared(float n, float d, float r) {   // the compiler's five qu
     return __builtin_fmaf(e, r, q);
 }
 PT_DEV float div_exact3(float n, float d, float r) {
+#if PT_PLAIN_DIV
+    return n / d;
+#endif
     float q0 = n * r;
     float q = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0);
     return (n == 0.0f) ? q0 : q;

@@ -186,8 +186,13 @@ PT_DEV bool slab1_fast(float lo, float hi, float o, float d, float r, BoxHit& h,
         t1 = div_exact3(hi - o, d, r);
     } else {
         const float n0 = lo - o, n1 = hi - o, q0 = n0 * r, q1 = n1 * r;
+#if PT_PLAIN_DIV
+        t0 = n0 / d;
+        t1 = n1 / d;
+#else
         t0 = __builtin_fmaf(__builtin_fmaf(-d, q0, n0), r, q0);
         t1 = __builtin_fmaf(__builtin_fmaf(-d, q1, n1), r, q1);
+#endif
         // Inside the guard windows both quotients are finite (no NaN), and correctly rounded division is monotonic, so "the plane
         // the ray meets first" (d < 0 ? t1 : t0) IS min(t0, t1) and the other one max(t0, t1); OpenCL's min / max select forms then
         // agree with v_min_f32 / v_max_f32 up to the sign of a zero, which nothing downstream can see (compare-only).  Six full-rate
