@@ -1237,7 +1237,7 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
         mirt_buf* pb = g->prims;
         if ((rc = ensure_prepared(ctx, pb, g->cell_offsets->off_last))) return rc;
         o->prims = pb->prep ? pb->prep : pb->ptr;
-        o->pnorm = pb->prep ? (const char*)pb->prep + pt::prepared_normals_offset(g->cell_offsets->off_last) : nullptr;
+        o->pnorm = pb->prep && g->cell_offsets->off_last <= pt::kLdsTriMax ? (const char*)pb->prep + pt::prepared_planes_offset(g->cell_offsets->off_last) : nullptr;
     }
     o->normals = tri ? g->normals->ptr : nullptr;
     o->matid = per_prim_matid ? g->matid->ptr : nullptr;

@@ -55,20 +55,6 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
     out[3u * i] = make_float4(p0.x, p0.y, p0.z, n.x);
     out[3u * i + 1] = make_float4(e1.x, e1.y, e1.z, n.y);
     out[3u * i + 2] = make_float4(e2.x, e2.y, e2.z, n.z);
-    // the candidate sweep's array (pt_trace.hpp trace_cell1): {n, k = p0 . n} and the margin constants of the plane window,
-    // M = G |o|_1 + H = 2^-17 |e1|_1 |e2|_1 (|o|_1 + |p0|_1), each product rounded up, H at least 2^-56
-    float4* pn = (float4*)((char*)out + prepared_normals_offset(count));
-    {
-        const float up = 1.0000002384185791015625f;   // 1 + 2^-22: more than the rounding of the sums and products below
-        const float k = (float)((double)p0.x * n.x + (double)p0.y * n.y + (double)p0.z * n.z);
-        const float E = ((__builtin_fabsf(e1.x) + __builtin_fabsf(e1.y) + __builtin_fabsf(e1.z)) * up) * ((__builtin_fabsf(e2.x) + __builtin_fabsf(e2.y) + __builtin_fabsf(e2.z)) * up) * up;
-        const float G = 0x1p-17f * E;
-        const float H = __builtin_fmaxf(G * ((__builtin_fabsf(p0.x) + __builtin_fabsf(p0.y) + __builtin_fabsf(p0.z)) * up) * up, 0x1p-56f);
-        pn[2u * i] = make_float4(n.x, n.y, n.z, k);
-        pn[2u * i + 1] = make_float4(G, H, 0.0f, 0.0f);
-    }
-    if (i == count - 1u)
-        for (uint32_t k = 2u * count; (k & 7u) != 0u; ++k) pn[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto bad = [](float v) { const float a = __builtin_fabsf(v); return !(v == 0.0f || (a >= 9.094947e-13f && a <= 1.0995116e12f)); };
     // ... and every vertex / edge component within 2^21 in magnitude (NaN fails): the bounds of the set are the caller's word, the
     // finiteness arguments of the optimistic kernel (pt_trace.hpp) are about the triangles themselves
@@ -98,6 +84,55 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
         // interval test rejects -- skipping it changes nothing; an infinite one makes the radius infinite: never skipped)
         ((float4*)(out + 3u * (size_t)count))[i / kTriGroup] = make_float4(c.x, c.y, c.z, r * r);
     }
+}
+
+// The candidate sweep's plane list of a small set (count <= kLdsTriMax; GridArgs::pnorm), from the prepared records.  One entry per RUN of
+// consecutive records whose plane is the same bit for bit -- n = cross(e2, e1) and k = p0 . n equal: the two halves of a quad -- so the
+// sweep evaluates that plane once and shifts its verdict in for both (cornell.xml: 12 triangles, 7 planes).  A run never crosses a chunk
+// of 32 records (one candidate word).  Entry: {n, k} {G, H, run, 0} with the margin constants of the plane window,
+// M = G |o|_1 + H = 2^-17 |e1|_1 |e2|_1 (|o|_1 + |p0|_1), each product rounded up, H at least 2^-56; a run takes the larger G and H of
+// its records (a wider margin is always safe).  Serial: at most 128 records, once per buffer content.
+__global__ void __launch_bounds__(64) k_planeRuns(const float4* prep, uint32_t count, float4* planes) {
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    uint32_t* hdr = (uint32_t*)planes;
+    float4* ent = planes + 4;   // the header is 64 bytes
+    const float up = 1.0000002384185791015625f;   // 1 + 2^-22: more than the rounding of the sums and products below
+    auto make = [&](uint32_t i, float4& a, float4& b) {
+        const float4 A = prep[3u * i], B = prep[3u * i + 1], C = prep[3u * i + 2];
+        const float k = (float)((double)A.x * A.w + (double)A.y * B.w + (double)A.z * C.w);
+        const float E = ((__builtin_fabsf(B.x) + __builtin_fabsf(B.y) + __builtin_fabsf(B.z)) * up) * ((__builtin_fabsf(C.x) + __builtin_fabsf(C.y) + __builtin_fabsf(C.z)) * up) * up;
+        const float G = 0x1p-17f * E;
+        const float H = __builtin_fmaxf(G * ((__builtin_fabsf(A.x) + __builtin_fabsf(A.y) + __builtin_fabsf(A.z)) * up) * up, 0x1p-56f);
+        a = make_float4(A.w, B.w, C.w, k);
+        b = make_float4(G, H, 0.0f, 0.0f);
+    };
+    auto same = [](const float4& x, const float4& y) {
+        return __float_as_uint(x.x) == __float_as_uint(y.x) && __float_as_uint(x.y) == __float_as_uint(y.y) && __float_as_uint(x.z) == __float_as_uint(y.z) &&
+               __float_as_uint(x.w) == __float_as_uint(y.w);
+    };
+    uint32_t np = 0;
+    for (uint32_t c = 0; c < 4u; ++c) {
+        const uint32_t lo = c * 32u, hi = lo + 32u < count ? lo + 32u : count;
+        hdr[4u + c] = np;
+        for (uint32_t i = lo; i < hi;) {
+            float4 a, b;
+            make(i, a, b);
+            uint32_t run = 1u;
+            if (i + 1u < hi) {
+                float4 a2, b2;
+                make(i + 1u, a2, b2);
+                if (same(a, a2)) { run = 2u; b.x = __builtin_fmaxf(b.x, b2.x); b.y = __builtin_fmaxf(b.y, b2.y); }
+            }
+            b.z = __uint_as_float(run);
+            ent[2u * np] = a;
+            ent[2u * np + 1u] = b;
+            ++np;
+            i += run;
+        }
+        hdr[c] = lo < count ? np - hdr[4u + c] : 0u;
+        if (np & 1u) { ent[2u * np] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ent[2u * np + 1u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ++np; }   // run = 0: shifts nothing in
+    }
+    for (uint32_t c = 8u; c < 16u; ++c) hdr[c] = 0u;
 }
 
 // Cold per-ray state parked in LDS instead of registers: the accumulator (touched once per shading event) and the
@@ -504,10 +539,11 @@ void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint
     if (words) hipLaunchKernelGGL(k_deferCount, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, count);
 }
 
-size_t prepared_bytes(uint32_t count) { return prepared_normals_offset(count) + (((size_t)count + 3) & ~(size_t)3) * 32; }
+size_t prepared_bytes(uint32_t count) { return prepared_planes_offset(count) + (count <= kLdsTriMax ? 64 + ((size_t)count + 8) * 32 : 0); }
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word) {
     if (!count) return;
     hipLaunchKernelGGL(k_prepTriangles, dim3((count + 255) / 256), dim3(256), 0, s, (const float4*)pos, (float4*)out, count, insane_word);
+    if (count <= kLdsTriMax) hipLaunchKernelGGL(k_planeRuns, dim3(1), dim3(64), 0, s, (const float4*)out, count, (float4*)((char*)out + prepared_planes_offset(count)));
 }
 
 }  // namespace pt

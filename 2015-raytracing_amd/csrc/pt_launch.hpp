@@ -38,9 +38,11 @@ constexpr uint32_t kLdsOffWords = 4096;   // 16 KB of LDS per block for cell-off
 constexpr uint32_t kLdsTriMax = 128;      // single-cell triangle sets staged in LDS for the per-lane candidate loops: 6 KB per block at most
 struct GridArgs {            // one cell-sorted primitive set, device pointers
     const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per PREPARED triangle (launch_prepTriangles)
-    const void* pnorm;       // triangles: two float4 per prepared record, {n.xyz, k} {G, H, 0, 0}: n = cross(e2, e1), k = p0 . n, and the two
-                             // constants of the plane-window margin M = G |o|_1 + H -- the sweep array behind the records and group spheres
-                             // (prepared_normals_offset), read by scalar loads in the candidate sweep (pt_trace.hpp trace_cell1)
+    const void* pnorm;       // triangles, at most kLdsTriMax records: the candidate sweep's PLANE list behind the records and group spheres
+                             // (prepared_planes_offset; k_planeRuns writes it): a 64-byte header {planes[4], first[4]} per chunk of 32 records, then
+                             // 32 bytes per plane {n.xyz, k = p0 . n, G, H, run, 0}: n = cross(e2, e1), the two constants of the plane-window margin
+                             // M = G |o|_1 + H, and how many CONSECUTIVE records (1 or 2: the halves of a quad) lie in it bit for bit.  Read by scalar
+                             // loads in the sweep (pt_trace.hpp trace_cell1).  Null: no list (the set runs the wave-uniform loop)
     const void* normals;     // 3 x float4 per triangle (null for spheres)
     const void* matid;       // uint per primitive (null: use `mesh_matid`)
     const void* off;         // uint[n^3 + 1]
@@ -88,16 +90,17 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
 bool fused_fast_available();   // compiled with PT_EXACT_FAST_DIV
 void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count);
 // {p0,e1,e2,n} records from the host's 3 x float4 position buffer (see pt_kernels_fused.hip); `out` holds count records of 48 B,
-// behind them ceil(count / kTriGroup) float4 {centre, R'^2}: the bounding spheres of groups of consecutive records, and behind those
-// the candidate sweep's array, 2 float4 per record {n, k} {G, H, 0, 0}
+// behind them ceil(count / kTriGroup) float4 {centre, R'^2}: the bounding spheres of groups of consecutive records, and behind those, for
+// count <= kLdsTriMax, the candidate sweep's plane list (GridArgs::pnorm)
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word);
 size_t prepared_bytes(uint32_t count);   // what `out` must hold for `count` triangles
 #ifndef PT_TRI_GROUP
 #define PT_TRI_GROUP 16
 #endif
 constexpr uint32_t kTriGroup = PT_TRI_GROUP;   // prepared records per bounding sphere (pt_trace.hpp group_missed)
-// byte offset of the candidate sweep's array inside it: 32 bytes per record, 64-byte aligned and zero-padded to a multiple of four records
-__host__ __device__ inline size_t prepared_normals_offset(uint32_t count) { return ((size_t)count * 48 + ((size_t)count + kTriGroup - 1) / kTriGroup * 16 + 63) & ~(size_t)63; }
+// byte offset of the candidate sweep's plane list inside it (64-byte aligned): header, then at most count + 8 entries of 32 bytes (every chunk's
+// run of entries starts at an even index and is padded to an even length: two entries per s_load_dwordx16)
+__host__ __device__ inline size_t prepared_planes_offset(uint32_t count) { return ((size_t)count * 48 + ((size_t)count + kTriGroup - 1) / kTriGroup * 16 + 63) & ~(size_t)63; }
 
 // ---- uniform-grid build on the device (pt_grid_build.hip) -------------------------------------------
 constexpr uint64_t kMaxGridSlots = 0x7FFFFFFFull;   // (cell, primitive) slots one grid may hold: the sort and every consumer index them with 31 bits

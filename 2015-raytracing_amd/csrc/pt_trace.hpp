@@ -338,9 +338,9 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     const uint32_t end = __builtin_amdgcn_readfirstlane(ldc_u32(S.off, 1));
     bool done = false;
     if (LANES && KIND == TRIANGLES && FAST && RULE == TRI_A10 && S.lds_off != kNoLds && begin == 0u) {
-        // the sweep's array: two float4 per triangle, {n.xyz, k = p0.n} {G, H, 0, 0} (k_prepTriangles), two triangles per s_load_dwordx16;
-        // padded to a multiple of four triangles, zero-filled
-        const pt_v16f PT_CONST_AS* pn = (const pt_v16f PT_CONST_AS*)S.pnorm;
+        // the sweep's plane list (k_planeRuns): a 64-byte header {planes[4], first[4]} per chunk of 32 records, then one entry per run of
+        // consecutive records in one plane: {n.xyz, k = p0.n} {G, H, run, 0}; two entries per s_load_dwordx16
+        const pt_v16f PT_CONST_AS* pn = (const pt_v16f PT_CONST_AS*)((const char PT_CONST_AS*)S.pnorm + 64);
         const uint32_t lds_bytes = S.lds_off * 4u;
 #if PT_LANE_FILTER
         // PLANE WINDOW (the second filter of the sweep).  A hit needs cmin <= t <= cmax and t < maxt (code.cl:273-280 and the callers'
@@ -362,12 +362,16 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         const float lo_m = cmin * 0.99999904632568359375f;
 #endif
         for (uint32_t c0 = 0u; c0 < end; c0 += 32u) {
-            const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u, quads = (cnt + 3u) >> 2;
+            const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u;
+            const uint32_t planes = ldc_u32(S.pnorm, c0 >> 5), first = ldc_u32(S.pnorm, 4u + (c0 >> 5));
             uint32_t neg = 0u;
-            for (uint32_t g = 0; g < 2u * quads; ++g) {
-                const pt_v16f v = pn[(c0 >> 1) + g];
+            for (uint32_t g = 0; g < (planes + 1u) >> 1; ++g) {
+                const pt_v16f v = pn[(first >> 1) + g];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
+                    const uint32_t run = __float_as_uint(v[8 * k + 6]);   // wave-uniform (an SGPR): 1 or 2 records in this plane, 0 for the padding entry
+                    if (run == 0u) continue;
+                    asm volatile("" ::: "memory");   // keeps the skip a scalar branch (the compiler would rather compute the padding entry and select)
                     const float div = dot3(mk3(v[8 * k], v[8 * k + 1], v[8 * k + 2]), ray.d);
 #if PT_LANE_FILTER
                     const float sn = cl_fma(v[8 * k + 2], ray.o.z, cl_fma(v[8 * k + 1], ray.o.y, cl_fma(v[8 * k], ray.o.x, -v[8 * k + 3])));
@@ -377,11 +381,11 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
 #else
                     const float w = div;
 #endif
-                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(w), 31);   // (neg << 1) | sign
+                    // (neg << run) | the sign, once per record of the run
+                    neg = (neg << run) | ((uint32_t)((int32_t)__float_as_uint(w) >> 31) & ((1u << run) - 1u));
                 }
             }
-            // triangle c0 + k at bit 31 - k; the padding of the last quad (div = 0: sign clear) is masked off
-            uint32_t cand = (~neg << (32u - 4u * quads)) & (0xFFFFFFFFu << (32u - cnt));
+            uint32_t cand = ~neg << (32u - cnt);   // record c0 + k at bit 31 - k
             if (ANY && done) cand = 0u;            // (a set of more than 32 triangles: a blocked lane sits the later sweeps out)
             while (cand != 0u) {
                 const uint32_t k = (uint32_t)__builtin_clz(cand);
