@@ -29,15 +29,24 @@ PT_DEV float dot3(f3 a, f3 b) { return cl_fma(a.z, b.z, cl_fma(a.y, b.y, a.x * b
 PT_DEV f3 cross3(f3 a, f3 b) {
     return mk3(cl_fma(a.y, b.z, -(a.z * b.y)), cl_fma(a.z, b.x, -(a.x * b.z)), cl_fma(a.x, b.y, -(a.y * b.x)));
 }
+// The library's corner cases (dot below 2^-126, infinite, NaN, zero vector) are rare-lane overrides of the plain result: written with
+// the plain path first, the compiler keeps it three or four instructions long (as two branches of an if it merged the tails and every
+// lane ran the rescaling selects).  One unsigned compare tells the cases apart: dot(v, v) is never negative, so "normal and finite" is
+// bits - 2^-126's bits < inf's bits - 2^-126's bits (zero wraps to the top; inf and NaN sit at or above the bound).
+PT_DEV bool dot_plain(float d) { return __float_as_uint(d) - 0x00800000u < 0x7F000000u; }
 PT_DEV float len3(f3 a) {
     const float d = dot3(a, a);
-    if (__builtin_expect(d < 0x1p-126f, 0)) { const f3 b = scl3(0x1p+86f, a); return cl_sqrt_approx(dot3(b, b)) * 0x1p-86f; }
-    if (__builtin_expect(d == PT_INF_, 0)) { const f3 b = scl3(0x1p-66f, a); return cl_sqrt_approx(dot3(b, b)) * 0x1p+66f; }
-    return __builtin_amdgcn_sqrtf(d);
+    float r = __builtin_amdgcn_sqrtf(d);
+    if (__builtin_expect(!dot_plain(d), 0)) {
+        if (d < 0x1p-126f) { const f3 b = scl3(0x1p+86f, a); r = cl_sqrt_approx(dot3(b, b)) * 0x1p-86f; }
+        else if (d == PT_INF_) { const f3 b = scl3(0x1p-66f, a); r = cl_sqrt_approx(dot3(b, b)) * 0x1p+66f; }
+    }
+    return r;
 }
 PT_DEV f3 norm3(f3 a) {
     float d = dot3(a, a);
-    if (__builtin_expect(!(d >= 0x1p-126f && d < PT_INF_), 0)) {   // the library's corner cases, in its order
+    f3 r = scl3(__builtin_amdgcn_rsqf(d), a);
+    if (__builtin_expect(!dot_plain(d), 0)) {   // the library's corner cases, in its order
         if (a.x == 0.0f && a.y == 0.0f && a.z == 0.0f) return a;
         if (d < 0x1p-126f) { a = scl3(0x1p+86f, a); d = dot3(a, a); }
         else if (d == PT_INF_) {
@@ -48,9 +57,9 @@ PT_DEV f3 norm3(f3 a) {
                 d = dot3(a, a);
             }
         }
-        return scl3(cl_rsqrt(d), a);
+        r = scl3(cl_rsqrt(d), a);
     }
-    return scl3(__builtin_amdgcn_rsqf(d), a);
+    return r;
 }
 PT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 PT_DEV f3 ld3(const float4& v) { return mk3(v.x, v.y, v.z); }
@@ -101,7 +110,9 @@ PT_DEV void concentric(float inx, float iny, float& ox, float& oy) {
     float b = cl_fma(2.0f, iny, -1.0f);
     const bool top = (a * a) > (b * b);
     float radius = top ? (1.0f * a) : (1.0f * b);
-    float q = top ? (b / a) : (a / b);
+    const float num = top ? b : a, den = top ? a : b;
+    float q = num / den;   // code.cl:158, 163: b / a or a / b -- one division on the selected operands (written as a select of two
+                           // quotients the compiler evaluates both: eleven instructions per call for nothing)
     float phi = top ? (PT_PI_4 * q) : cl_fma(-PT_PI_4, q, PT_PI_2);   // code.cl:164: c - a*b contracts to fma(-a, b, c)
     float s, c;
     cl_sincos(phi, s, c);

@@ -206,10 +206,19 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const PARK& park
             poi.n = norm3(sub3(poi.p, ld3(((const float4*)S.prims)[ch.idx])));
             poi.matId = (int32_t)((const uint32_t*)S.matid)[ch.idx];
         } else {
-            const float4* nn = (const float4*)S.normals + 3u * (size_t)ch.idx;
             float w = 1.0f - ch.beta - ch.gamma;  // code.cl:409-411
-            poi.n = norm3(fma3(ch.gamma, ld3(nn[2]), fma3(w, ld3(nn[0]), scl3(ch.beta, ld3(nn[1])))));
-            poi.matId = (int32_t)(S.matid ? ((const uint32_t*)S.matid)[ch.idx] : S.mesh_matid);
+            if (PT_LANE_LISTS_FOR(FAST, GRIDS) && S.n == 1u && S.lds_off != kNoLds) {
+                // a set staged for the candidate loops carries its vertex normals and material ids in LDS too: three ds_read_b128 and a
+                // ds_read_b32 instead of four dependent global loads between the hit and the bounce
+                const uint32_t base = S.lds_off + 12u * S.nslots;
+                const float4* nn = (const float4*)&pt_lds_dyn[base + __umul24(ch.idx, 12u)];
+                poi.n = norm3(fma3(ch.gamma, ld3(nn[2]), fma3(w, ld3(nn[0]), scl3(ch.beta, ld3(nn[1])))));
+                poi.matId = (int32_t)pt_lds_dyn[base + 12u * S.nslots + ch.idx];
+            } else {
+                const float4* nn = (const float4*)S.normals + 3u * (size_t)ch.idx;
+                poi.n = norm3(fma3(ch.gamma, ld3(nn[2]), fma3(w, ld3(nn[0]), scl3(ch.beta, ld3(nn[1])))));
+                poi.matId = (int32_t)(S.matid ? ((const uint32_t*)S.matid)[ch.idx] : S.mesh_matid);
+            }
         }
 #if PT_PARK_LDS
         if (PT_PARK_PN_FOR(GRIDS)) park.put_pn(poi);
@@ -310,9 +319,13 @@ PT_DEV void stage_block(const FusedArgs& A) {
             if (S.lds_off == kNoLds) continue;
             if (S.n == 1u) {
                 if (!PT_LANE_LISTS_FOR(FAST, GRIDS)) continue;
+                // [records 12 words each][vertex normals 12 words each][material ids, one word each: a mesh's single id repeated]
                 const uint32_t words = S.nslots * 12u;
                 const uint32_t* src = (const uint32_t*)S.prims;
-                for (uint32_t k = threadIdx.x; k < words; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
+                const uint32_t* nrm = (const uint32_t*)S.normals;
+                const uint32_t* mid = (const uint32_t*)S.matid;
+                for (uint32_t k = threadIdx.x; k < words; k += 256u) { pt_lds_dyn[S.lds_off + k] = src[k]; pt_lds_dyn[S.lds_off + words + k] = nrm[k]; }
+                for (uint32_t k = threadIdx.x; k < S.nslots; k += 256u) pt_lds_dyn[S.lds_off + 2u * words + k] = mid ? mid[k] : S.mesh_matid;
             } else if (GRIDS == 1) {
                 const uint32_t words = S.n * S.n * S.n + 1u;
                 const uint32_t* src = (const uint32_t*)S.off;
@@ -515,9 +528,9 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
     if (fast && PT_LANE_LISTS_FOR(true, grids ? 1 : 0)) {
         for (uint32_t i = 0; i < b.n_sets; ++i) {
             GridArgs& S = b.sets[i];
-            if (S.n != 1u || S.kind != KIND_TRIANGLES || !S.pnorm || S.nslots == 0u || tri_words / 12u + S.nslots > kLdsTriMax) continue;
+            if (S.n != 1u || S.kind != KIND_TRIANGLES || !S.pnorm || S.nslots == 0u || tri_words / 28u + S.nslots > kLdsTriMax) continue;
             S.lds_off = tri_base4 + tri_words;
-            tri_words += S.nslots * 12u;
+            tri_words += S.nslots * 28u;   // records, vertex normals, material ids (stage_block), rounded up to whole float4s
         }
     }
     const dim3 grid((unsigned)((n + 255) / 256));

@@ -35,7 +35,8 @@ constexpr int kMaxMeshes = 16;
 
 constexpr uint32_t kNoLds = 0xFFFFFFFFu;
 constexpr uint32_t kLdsOffWords = 4096;   // 16 KB of LDS per block for cell-offset tables (n <= 15 for a single grid)
-constexpr uint32_t kLdsTriMax = 128;      // single-cell triangle sets staged in LDS for the per-lane candidate loops: 6 KB per block at most
+constexpr uint32_t kLdsTriMax = 96;       // single-cell triangle sets staged in LDS for the per-lane candidate loops (records, vertex normals, material ids:
+                                          // 112 B per triangle): 10.5 KB per block at most
 struct GridArgs {            // one cell-sorted primitive set, device pointers
     const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per PREPARED triangle (launch_prepTriangles)
     const void* pnorm;       // triangles, at most kLdsTriMax records: the candidate sweep's PLANE list behind the records and group spheres

@@ -223,6 +223,28 @@ PT_DEV RayRcp ray_rcp(const Ray& r) {
 }
 template <bool FAST, bool SIGNED_ZERO = true>
 PT_DEV BoxHit inter_aabb_t(const Ray& r, const RayRcp& q, const Box& b) {
+    if (FAST && !SIGNED_ZERO) {
+        // compare-only users (the single-cell sets).  tmin only grows and tmax only shrinks from slab to slab and neither is ever a NaN
+        // (min / max drop a NaN operand and the chains start at 0 and inf), so the reference's three early returns (code.cl:351-354,
+        // 366-369, 381-384) say no exactly when the final pair does: one comparison, and the chains as v_max3_f32 / v_min3_f32.  Inside
+        // the guard windows every quotient is finite, so the chain's leading min(inf, .) is the identity; the sign of a zero is invisible
+        // to comparisons (slab1_fast).
+        auto quo = [](float num, float d, float rr) { const float q0 = num * rr; return __builtin_fmaf(__builtin_fmaf(-d, q0, num), rr, q0); };
+        BoxHit h;
+#if PT_PLAIN_DIV
+        const float x0 = (b.lo.x - r.o.x) / r.d.x, x1 = (b.hi.x - r.o.x) / r.d.x, y0 = (b.lo.y - r.o.y) / r.d.y, y1 = (b.hi.y - r.o.y) / r.d.y;
+        const float z0 = (b.lo.z - r.o.z) / r.d.z, z1 = (b.hi.z - r.o.z) / r.d.z;
+#else
+        const float x0 = quo(b.lo.x - r.o.x, r.d.x, q.x), x1 = quo(b.hi.x - r.o.x, r.d.x, q.x);
+        const float y0 = quo(b.lo.y - r.o.y, r.d.y, q.y), y1 = quo(b.hi.y - r.o.y, r.d.y, q.y);
+        const float z0 = quo(b.lo.z - r.o.z, r.d.z, q.z), z1 = quo(b.hi.z - r.o.z, r.d.z, q.z);
+#endif
+        h.tfx = __builtin_fmaxf(x0, x1); h.tfy = __builtin_fmaxf(y0, y1); h.tfz = __builtin_fmaxf(z0, z1);
+        h.tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fmaxf(__builtin_fminf(z0, z1), 0.0f));
+        h.tmax = __builtin_fminf(__builtin_fminf(h.tfx, h.tfy), h.tfz);
+        h.v = !(h.tmin > h.tmax);
+        return h;
+    }
     if (FAST) {
         BoxHit h;
         h.tmin = 0.0f;
@@ -246,6 +268,12 @@ PT_DEV SphereRay sphere_ray(f3 d) {
     r.inv2a = FAST ? rcp_refined(2.0f * r.a) : (1.0f / (2.0f * r.a));
     return r;
 }
+// ORDERED (the optimistic kernel): with a = d.d > 0 the two roots come out ordered, t0 = (-b - sq) / 2a <= t1 = (-b + sq) / 2a (sq >= 0 or NaN; sums
+// and products by a positive factor are monotonic under rounding), so fmin / fmax are the identity; the exact kernel keeps them (a ray
+// with infinite coordinates can make exactly one root a NaN).  `dis < 0` needs no test of its own anywhere: its square root is a NaN
+// (sqrt_core's v_sqrt_f32 and both neighbour residuals; the rare-lane path for tiny magnitudes is the library's sqrt), both roots are
+// NaNs and every window comparison below is false -- the reference's early return (code.cl:206-209) taken by arithmetic.
+template <bool ORDERED = false>
 PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, const float4 sph, float& t_out) {
     f3 omc = sub3(o, ld3(sph));
     float b = 2.0f * dot3(omc, d);
@@ -254,12 +282,12 @@ PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, co
     float sq = cl_sqrt(dis);
     float t0 = (-b - sq) * sr.inv2a;
     float t1 = (-b + sq) * sr.inv2a;
-    float tmin = cl_fmin(t0, t1);
-    float tmax = cl_fmax(t0, t1);
+    float tmin = ORDERED ? t0 : cl_fmin(t0, t1);
+    float tmax = ORDERED ? t1 : cl_fmax(t0, t1);
     const int in0 = (tmin >= cmin) & (tmin <= cmax);
     const int in1 = (tmax >= cmin) & (tmax <= cmax);
     t_out = in0 ? tmin : tmax;
-    return (!(dis < 0.0f) & (in0 | in1)) != 0;
+    return (in0 | in1) != 0;
 }
 
 // axis_setup (pt_device.hpp) with the optimistic kernel's divisions: every quotient is div_exact3 on a refined reciprocal.  The
@@ -418,7 +446,7 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         float ti, b = 0.0f, gm = 0.0f;
         bool hit;
         if (KIND == SPHERES) {
-            hit = sph_test(ray.o, ray.d, sr, cmin, cmax, ldc4((const void*)p, 0), ti);
+            hit = sph_test<FAST>(ray.o, ray.d, sr, cmin, cmax, ldc4((const void*)p, 0), ti);
         } else {
             hit = tri_test<RULE, FAST, PT_UNIFORM_CULL != 0>(ray.o, ray.d, cmin, cmax, ldc4((const void*)p, 0), ldc4((const void*)p, 1), ldc4((const void*)p, 2), ti, b, gm);
         }
