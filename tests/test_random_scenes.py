@@ -109,3 +109,65 @@ def test_random_scene_all_paths_agree(ctx, pkg, seed):
     assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds), "kernel by kernel"
     assert np.array_equal(got["pois"]["matId"], st.pois["matId"])
     gr.release()
+
+
+def quad_scene(base, seed, n_tris):
+    """Loose triangles that come in coplanar PAIRS (the halves of rectangles, same winding: bit-identical plane normals where the
+    arithmetic is exact, nearly identical elsewhere), as scenes built from quads have them; an odd count leaves a single at the end.
+    Sizes around the 32-record chunks of the candidate sweep, so a pair straddles a chunk boundary (records 31 | 32, 63 | 64)."""
+    rng = np.random.default_rng(seed)
+    d = dict(base.d)
+    nmat = len(d["materials"]) // 4
+    v = np.zeros((n_tris, 3, 3), np.float32)
+    nrm = np.zeros((n_tris, 3, 3), np.float32)
+    k = 0
+    while k < n_tris:
+        axis_aligned = rng.random() < 0.6
+        c = rng.uniform(-0.8, 0.8, size=3)
+        if axis_aligned:   # exact arithmetic: coordinates on a 1/64 lattice, edges along two axes
+            ax = int(rng.integers(0, 3))
+            u, w = np.zeros(3), np.zeros(3)
+            u[(ax + 1) % 3] = float(rng.integers(2, 40)) / 64.0
+            w[(ax + 2) % 3] = float(rng.integers(2, 40)) / 64.0
+            c = np.round(c * 64.0) / 64.0
+            if rng.random() < 0.5:
+                u, w = w, u
+        else:
+            u, w = rng.normal(size=3) * 0.3, rng.normal(size=3) * 0.3
+        p = [c, c + u, c + u + w, c + w]
+        n = np.cross(w, u)
+        n = n / (np.linalg.norm(n) + 1e-30)
+        for tri in ((p[0], p[1], p[2]), (p[0], p[2], p[3])):
+            if k < n_tris:
+                v[k] = np.asarray(tri, np.float32)
+                nrm[k] = n.astype(np.float32)
+                k += 1
+    b8 = _bbox8(v.reshape(-1, 3).min(axis=0) - 0.01, v.reshape(-1, 3).max(axis=0) + 0.01)
+    off, order = expected_grid(1, v.reshape(n_tris, 9).astype(np.float64), [b8[0], b8[1], b8[2], b8[4], b8[5], b8[6]], 1)
+    assert np.array_equal(order, np.arange(n_tris))      # one cell: upload order kept, pairs stay adjacent
+    pos, nor = _pack_tris(v, nrm, order)
+    out = {"n_slabs": 1, "n_spheres": 0, "spheres": [], "s_matid": [], "s_box": [0, 0], "n_triangles": n_tris, "t_pos": pos, "t_normal": nor,
+           "t_matid": rng.integers(0, nmat, size=n_tris).tolist(), "t_box": off.tolist(), "triangle_bounds": b8, "meshes": [],
+           "lights": [d["lights"][0]]}
+    return _variant(base, width=64, height=36, rays_per_pixel=4, **out)
+
+
+@pytest.mark.parametrize("n_tris", [2, 12, 31, 33, 63, 65, 95, 96, 97])
+def test_quad_soups_through_the_plane_runs(ctx, pkg, n_tris):
+    """The candidate sweep's plane list (k_planeRuns): runs of two records in one plane, chunk boundaries inside a pair, the last
+    staged size (96) and the first that falls back to the wave-uniform loop (97) -- optimistic pair == exact kernel == CPU oracle."""
+    from raytracing_amd.pyhost import render
+    _, base = load_fixture("cornell_32x24_r4")
+    sc = quad_scene(base, 77 + n_tris, n_tris)
+    seeds = A.make_seeds(sc.total_rays, seed_base=n_tris)
+    st = A.PassState(sc, seeds)
+    A.run_pass(A.load_oracle(), sc, st, bounces=8)
+    for exact_only in (False, True):
+        ctx.set_exact_only(exact_only)
+        fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+        fr.execute_render(bounces=8)
+        assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(st.acu)), f"fused, exact_only={exact_only}"
+        assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
+        fr.release()
+    ctx.set_exact_only(False)
+    assert (st.acu[:, 3] > 0).any()       # the soup is hit
