@@ -484,17 +484,22 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
         asm volatile("" : "+v"(t));
         lid = (uint64_t)blockIdx.x * 256u + t;
     }
+    // The optimistic kernel has one sample per thread: it LEAVES here, so the compiler sees a straight-line body and not a loop (the
+    // exact kernel's redo mode does loop over the set bits of its word).  As a loop -- its exit in the grid kernels is a wave ballot, opaque
+    // to the compiler -- every sample-independent value of the body (the camera set-up, sqrt(rpp), the lens-grid reciprocals ...) was
+    // hoisted out and kept alive through the whole path: that was what the grid kernels spilled.
     if (FAST && defer) {   // hand the sample to the exact kernel: its inputs stay as they were
         if (valid) atomicOr(&defer_mask[lid >> 5], 1u << (lid & 31u));
-        if (!GRIDS) return;
-        continue;
+        return;
     }
-    if (!valid) continue;
-    A.seeds[lid] = seed;
+    if (valid) {
+        A.seeds[lid] = seed;
 #if PT_PARK_LDS
-    acc = make_float4(park.get(0), park.get(1), park.get(2), park.get(3));
+        acc = make_float4(park.get(0), park.get(1), park.get(2), park.get(3));
 #endif
-    ((float4*)A.acu)[lid] = acc;
+        ((float4*)A.acu)[lid] = acc;
+    }
+    if (FAST) return;
   }
 }
 
