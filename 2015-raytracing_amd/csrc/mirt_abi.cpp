@@ -1294,7 +1294,7 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     if (d->row0 >= d->height || nrows > d->height - d->row0) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: row tile [%u,+%u) outside the image", d->row0, nrows);
     const uint64_t npix = (uint64_t)nrows * d->width;
     const uint64_t nrays = npix * d->rays_per_pixel;
-    if (nrays > 0xFFFFFFFFull) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: %llu rays in one tile; split the rows over more launches", (unsigned long long)nrays);
+    if (nrays > 0xFFFFFF00ull) return fail(ctx, MIRT_E_ARG, "mirt_render_pass: %llu rays in one tile (the kernels index a tile's rays with 32 bits); split the rows over more launches", (unsigned long long)nrays);
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
     pt::FusedArgs A;

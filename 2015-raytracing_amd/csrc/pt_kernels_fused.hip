@@ -337,11 +337,12 @@ PT_DEV void stage_block(const FusedArgs& A) {
 }
 
 // initTrace (code.cl:458-543) for one ray id of the tile: thin-lens ray through its pixel, clipped to the scene box
-PT_DEV Ray primary_ray(const FusedArgs& A, uint64_t lid) {
-    const uint64_t lpix = lid / A.rpp;
-    const uint32_t smp = (uint32_t)(lid - lpix * A.rpp);
-    const uint32_t lrow = (uint32_t)(lpix / A.width);
-    const uint32_t col = (uint32_t)(lpix - (uint64_t)lrow * A.width);
+// (tile-local ray ids fit 32 bits: mirt_render_pass refuses a tile of more than 2^32 - 256 rays)
+PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
+    const uint32_t lpix = lid / A.rpp;
+    const uint32_t smp = lid - lpix * A.rpp;
+    const uint32_t lrow = lpix / A.width;
+    const uint32_t col = lpix - lrow * A.width;
     const uint32_t row = A.row0 + lrow;
     Cam cam;
     cam.eye = ld3(A.cam); cam.U = ld3(A.cam + 3); cam.V = ld3(A.cam + 6); cam.W = ld3(A.cam + 9);
@@ -420,11 +421,13 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
     bool valid = todo != 0u;
     if (GRIDS) { if (__builtin_amdgcn_ballot_w64(valid) == 0ull) break; }
     else if (!valid) break;
-    uint64_t lid = base + (valid ? (uint32_t)__builtin_ctz(todo) : 0u);
-    if (lid >= n_local) {
+    // the id is checked in 64 bits (the last block of a tile of nearly 2^32 rays reaches past it) and kept in 32
+    const uint64_t lid64 = base + (valid ? (uint32_t)__builtin_ctz(todo) : 0u);
+    uint32_t lid = (uint32_t)lid64;
+    if (lid64 >= n_local) {
         if (!GRIDS) return;
         valid = false;
-        lid = n_local - 1u;
+        lid = (uint32_t)(n_local - 1u);
     }
     bool defer = false;
     int32_t seed = A.seeds[lid];
@@ -477,12 +480,14 @@ __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT
         direct_all<FAST, GRIDS, Park>(A, poi, seed, acc, park, defer);
     }
 
-    if (FAST && !GRIDS) {
-        // the ray id again, from the thread index (one sample per thread in this kernel): re-deriving it here costs two instructions,
-        // keeping it (and the two 64-bit addresses made from it) alive across the whole path cost four spilled registers at 7 waves
+    if (FAST) {
+        // the ray id again, from the thread index (one sample per thread in this kernel): re-deriving it here costs a few instructions,
+        // keeping it (and the 64-bit addresses made from it) alive across the whole path cost spilled registers in every variant
         uint32_t t = threadIdx.x;
         asm volatile("" : "+v"(t));
-        lid = (uint64_t)blockIdx.x * 256u + t;
+        const uint64_t again = (uint64_t)blockIdx.x * 256u + t;
+        lid = (uint32_t)again;
+        if (GRIDS) valid = again < n_local;   // (a lane past the end of the tile rode along on the tile's last sample)
     }
     // The optimistic kernel has one sample per thread: it LEAVES here, so the compiler sees a straight-line body and not a loop (the
     // exact kernel's redo mode does loop over the set bits of its word).  As a loop -- its exit in the grid kernels is a wave ballot, opaque

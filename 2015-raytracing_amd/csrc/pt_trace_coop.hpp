@@ -22,6 +22,10 @@
 #pragma once
 #include "pt_trace.hpp"
 
+#ifndef PT_COOP_REMAT
+#define PT_COOP_REMAT 1
+#endif
+
 namespace pt {
 
 // One wave's exchange area in the block's dynamic LDS: CW_ROWS rows of 64 words, [row][lane]; 3 KB per wave, 12 KB per block, at
@@ -84,8 +88,13 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
     if (__builtin_amdgcn_ballot_w64(want) == 0ull) return ch;   // wave-uniform
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wbase = (threadIdx.x >> 6) * (CW_ROWS * 64u);
+    uint32_t tid = threadIdx.x;
+#if PT_COOP_REMAT
+    asm volatile("" : "+v"(tid));   // the exchange-row addresses are re-derived per walk (three instructions) instead of being hoisted out of the
+                                    // segment loop and kept alive -- in scratch, the one register the allocator had nowhere else to put
+#endif
+    const uint32_t lane = tid & 63u;
+    const uint32_t wbase = (tid >> 6) * (CW_ROWS * 64u);
 #define CW_MINE(row) pt_lds_dyn[wbase + (uint32_t)(row) * 64u + lane]
 #define CW_OF(row, l) pt_lds_dyn[wbase + (uint32_t)(row) * 64u + (l)]
     unsigned long long* const keys = (unsigned long long*)&pt_lds_dyn[wbase + (uint32_t)CW_KEY * 64u];
