@@ -101,8 +101,9 @@ def _unfused(ctx, sc, seeds, drive):
 
 def _define_struct_buffers(ctx, g):
     """The kernels leave parts of a Ray / Poi unwritten (o and d of a dead ray, p and normal of a vertex never hit: SURVEY 8a), i.e. whatever
-    the allocation held.  Zero them so that two runs can be compared byte for byte."""
-    for name in ("rays", "pois", "shadow"):
+    the allocation held -- and a stream that never reaches copyToPixel leaves the whole frame buffer that way.  Zero them so that two runs
+    can be compared byte for byte."""
+    for name in ("rays", "pois", "shadow", "pixel"):
         ctx.zero(g.b[name])
 
 
