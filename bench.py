@@ -77,7 +77,8 @@ def find_pmc_summary(path, workload_key, kernel_name):
             if path:
                 why = f"{c}: stamped for csrc {str(st.get('csrc_sha256'))[:12]} / {st.get('workload')}, this run is {want[:12]} / {workload_key}"
             continue
-        k = next((v for name, v in d.items() if name.startswith(kernel_name)), None)
+        squash = lambda t: t.replace(" ", "")      # rocprofv3 writes "void pt::k_fusedPass<true, 0>"
+        k = next((v for name, v in d.items() if squash(kernel_name) in squash(name)), None)
         if k is None:
             why = f"{c}: no counters for {kernel_name}"
             continue
