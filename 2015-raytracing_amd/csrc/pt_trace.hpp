@@ -47,6 +47,9 @@ enum TriRule { TRI_A10 = 0, TRI_A07 = 1, TRI_A04 = 2 };
 #ifndef PT_UNIFORM_CULL
 #define PT_UNIFORM_CULL 0
 #endif
+#ifndef PT_SPHERE_WAVE_SKIP
+#define PT_SPHERE_WAVE_SKIP 1
+#endif
 #ifndef PT_LANE_FILTER
 #define PT_LANE_FILTER 1   // the candidate sweep of trace_cell1 also drops triangles whose plane the ray meets outside its window
 #endif
@@ -273,12 +276,16 @@ PT_DEV SphereRay sphere_ray(f3 d) {
 // with infinite coordinates can make exactly one root a NaN).  `dis < 0` needs no test of its own anywhere: its square root is a NaN
 // (sqrt_core's v_sqrt_f32 and both neighbour residuals; the rare-lane path for tiny magnitudes is the library's sqrt), both roots are
 // NaNs and every window comparison below is false -- the reference's early return (code.cl:206-209) taken by arithmetic.
-template <bool ORDERED = false>
+// WAVE_SKIP (the wave-uniform loops: every lane holds the SAME sphere): when the discriminant is negative in every lane the square root and
+// the window tests are skipped for the wave -- the reference's early return (code.cl:206-209) taken when the whole wave takes it; a small
+// sphere is missed by all 64 rays of an incoherent wave about one time in five.
+template <bool ORDERED = false, bool WAVE_SKIP = false>
 PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, const float4 sph, float& t_out) {
     f3 omc = sub3(o, ld3(sph));
     float b = 2.0f * dot3(omc, d);
     float c = dot3(omc, omc) - sph.w;
     float dis = cl_mad(-4.0f * c, sr.a, b * b);
+    if (WAVE_SKIP && __builtin_amdgcn_ballot_w64(!(dis < 0.0f)) == 0ull) { t_out = 0.0f; return false; }
     float sq = cl_sqrt(dis);
     float t0 = (-b - sq) * sr.inv2a;
     float t1 = (-b + sq) * sr.inv2a;
@@ -409,8 +416,12 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
 #else
                     const float w = div;
 #endif
-                    // (neg << run) | the sign, once per record of the run
-                    neg = (neg << run) | ((uint32_t)((int32_t)__float_as_uint(w) >> 31) & ((1u << run) - 1u));
+                    // (neg << 1) | sign, once per record of the run (the second one behind a scalar branch)
+                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(w), 31);
+                    if (run >= 2u) {
+                        asm volatile("" ::: "memory");
+                        neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(w), 31);
+                    }
                 }
             }
             uint32_t cand = ~neg << (32u - cnt);   // record c0 + k at bit 31 - k
@@ -446,7 +457,7 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         float ti, b = 0.0f, gm = 0.0f;
         bool hit;
         if (KIND == SPHERES) {
-            hit = sph_test<FAST>(ray.o, ray.d, sr, cmin, cmax, ldc4((const void*)p, 0), ti);
+            hit = sph_test<FAST, PT_SPHERE_WAVE_SKIP != 0>(ray.o, ray.d, sr, cmin, cmax, ldc4((const void*)p, 0), ti);
         } else {
             hit = tri_test<RULE, FAST, PT_UNIFORM_CULL != 0>(ray.o, ray.d, cmin, cmax, ldc4((const void*)p, 0), ldc4((const void*)p, 1), ldc4((const void*)p, 2), ti, b, gm);
         }
