@@ -381,7 +381,8 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
 // FAST = false: the exact kernel (true divisions).  With `list` it recomputes the deferred samples; with list == nullptr it
 //               is the whole pass (geometry outside the guard, or PT_EXACT_FAST_DIV = 0).
 #ifndef PT_FUSED_WAVES_FAST
-#define PT_FUSED_WAVES_FAST 7   // the optimistic kernel without the grid walk: 72 VGPRs, no scratch (round 1, same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
+#define PT_FUSED_WAVES_FAST 8   // the optimistic kernel without the grid walk: 64 VGPRs, no scratch, since its body is straight-line (round 3: 7 -> 109.4 ms, 8 -> 107.7;
+                                // round 1, same box: 5 -> 216.7 ms, 6 -> 216.6, 7 -> 213.4, 8 -> 213.7 at depth 8)
 #endif
 // GRIDS = 0    : every set is a single cell (n == 1: the reference's loose spheres and triangles, A10 code.js:399): only the
 //                wave-uniform loops are compiled in.  Without the DDA the register allocator needs 72 VGPRs and no scratch
