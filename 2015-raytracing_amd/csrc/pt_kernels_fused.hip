@@ -311,8 +311,25 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 // per block, before any thread leaves: launch_fused gave every set that fits a slot (GridArgs::lds_off).  The primitives of a grid stay
 // in memory.  PT_LANE_LISTS: likewise the prepared records of the single-cell triangle sets launch_fused gave a slot (the candidate
 // loops fetch them per lane by ds_read_b128).
+// The k x k lens grid's coordinates (code.cl:482-509): coord = delta / 2 and then `+= delta` per step -- sample (i, j) of every pixel needs
+// the i-th and the j-th partial sum of that chain.  One thread walks the chain once per block and leaves the k values in LDS (as
+// every lane walking it to its own i and j it cost up to 2 (k - 1) dependent additions per sample: 30 of them at 256 rays per pixel, 62 at
+// 1024).  k > kLensTab: the lanes walk.
+constexpr uint32_t kLensTab = 64;
+__shared__ float pt_lens_tab[kLensTab];
+PT_DEV uint32_t lens_side(const FusedArgs& A) { return f2u(cl_sqrt((float)A.rpp)); }
+
 template <bool FAST, int GRIDS>
 PT_DEV void stage_block(const FusedArgs& A) {
+    if (A.rpp > 1u && threadIdx.x == 0u) {
+        const uint32_t side = lens_side(A);
+        if (side <= kLensTab) {
+            const float delta = 1.0f / (float)side;
+            float c = delta / 2.0f;
+            for (uint32_t k = 0; k < side; ++k) { pt_lens_tab[k] = c; c += delta; }
+        }
+    }
+    if (!(GRIDS == 1 || PT_LANE_LISTS_FOR(FAST, GRIDS))) __syncthreads();
     if (GRIDS == 1 || PT_LANE_LISTS_FOR(FAST, GRIDS)) {
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
@@ -356,13 +373,18 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
     if (A.rpp > 1) {
         // un-jittered k x k lens grid; coordinates accumulate by repeated addition in the
         // reference (coord += delta), so they are rebuilt the same way
-        const uint32_t side = f2u(cl_sqrt((float)A.rpp));
-        const float delta = 1.0f / (float)side;
+        const uint32_t side = lens_side(A);
         const uint32_t i = smp / side, j = smp - i * side;
-        cy = delta / 2.0f;
-        for (uint32_t k = 0; k < i; ++k) cy += delta;
-        cx = delta / 2.0f;
-        for (uint32_t k = 0; k < j; ++k) cx += delta;
+        if (side <= kLensTab) {   // the chain's partial sums, left in LDS by stage_block
+            cy = pt_lens_tab[i];
+            cx = pt_lens_tab[j];
+        } else {
+            const float delta = 1.0f / (float)side;
+            cy = delta / 2.0f;
+            for (uint32_t k = 0; k < i; ++k) cy += delta;
+            cx = delta / 2.0f;
+            for (uint32_t k = 0; k < j; ++k) cx += delta;
+        }
     } else {
         float2 c = ((const float2*)A.uv)[lpix];
         cx = c.x;
