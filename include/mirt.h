@@ -153,7 +153,8 @@ typedef struct mirt_light {         /* Light.to{Shadow,SceneRender,LightRender}I
 typedef struct mirt_pass_desc {
     uint32_t struct_size;           /* sizeof(mirt_pass_desc), for ABI evolution                   */
     uint32_t width, height, rays_per_pixel;
-    uint32_t row0, nrows;           /* row tile; nrows == 0 means the whole image                  */
+    uint32_t row0, nrows;           /* row tile; nrows == 0 means the whole image.  A tile holds at most 2^32 - 256 rays
+                                     * (nrows * width * rays_per_pixel: MIRT_E_ARG beyond; cut the rows over more calls) */
     uint32_t bounces;               /* 5 == reference (A10 code.js:1829)                           */
     uint32_t pass_index;            /* 1-based `passes` counter (A10 code.js:1850)                 */
     float cam[16];                  /* Camera.toFloat32Array, A10 code.js:250-258                  */
