@@ -198,7 +198,7 @@ MIRT_API int mirt_ctx_set_exact_only(mirt_ctx* ctx, int on);
  * exactly as at level 0: a different kernel order, mixed buffers or changed geometry arguments inside the pass, a global size
  * smaller than the ray count, and any command that observes or changes device state while enqueues are held (buffer read / write /
  * release, mirt_zero, mirt_seed_fill, mirt_render_pass, capture, timers, gather, destroy ...) flush the held stream first.
- * What level 2 trades, and why it is off by default:
+ * What level 2 trades, and why it is off by default in this ABI (the WebCL object model above it turns it on: end of this comment):
  *   - seeds, acu and pixel after the pass are bit-identical to level 0 (tests/test_fusion.py replays the reference host's own call
  *     stream both ways); the Ray, Poi and shadow-Ray buffers are NOT written by a fused pass -- they keep their previous contents.
  *     The reference host never reads them (it cannot: it does not know their layout beyond sizeof).
