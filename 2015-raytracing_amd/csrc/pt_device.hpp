@@ -87,7 +87,7 @@ PT_DEV Cam mk_cam(const F16& f) {
     Cam c;
     c.eye = ld3(f.v); c.U = ld3(f.v + 3); c.V = ld3(f.v + 6); c.W = ld3(f.v + 9);
     c.width = f.v[12]; c.height = f.v[13];
-    c.cols = f2u(f.v[14]); c.rows = f2u(f.v[15]);
+    c.cols = f2u_uniform(f.v[14]); c.rows = f2u_uniform(f.v[15]);
     return c;
 }
 

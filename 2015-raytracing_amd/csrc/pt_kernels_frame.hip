@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_a01_raytrace(uchar4* pixels, F16 cam, u
         else if (t1 > 0.0f && t1 < PT_INF) { t = t1; v = true; }
     }
     unsigned char base = v ? f2u8((1.0f - t) * 255.0f) : 0;
-    pixels[f2u(cols) * row + col] = make_uchar4(base, base, base, 255);
+    pixels[f2u_uniform(cols) * row + col] = make_uchar4(base, base, base, 255);
 }
 
 // ---- Assign04 / Assign07 initTrace ---------------------------------------------------------------

@@ -317,7 +317,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 // 1024).  k > kLensTab: the lanes walk.
 constexpr uint32_t kLensTab = 64;
 __shared__ float pt_lens_tab[kLensTab];
-PT_DEV uint32_t lens_side(const FusedArgs& A) { return f2u(cl_sqrt((float)A.rpp)); }
+PT_DEV uint32_t lens_side(const FusedArgs& A) { return f2u_uniform(cl_sqrt((float)A.rpp)); }
 
 template <bool FAST, int GRIDS>
 PT_DEV void stage_block(const FusedArgs& A) {
@@ -364,7 +364,7 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
     Cam cam;
     cam.eye = ld3(A.cam); cam.U = ld3(A.cam + 3); cam.V = ld3(A.cam + 6); cam.W = ld3(A.cam + 9);
     cam.width = A.cam[12]; cam.height = A.cam[13];
-    cam.cols = f2u(A.cam[14]); cam.rows = f2u(A.cam[15]);
+    cam.cols = f2u_uniform(A.cam[14]); cam.rows = f2u_uniform(A.cam[15]);
     Box bound;
     bound.lo = mk3(A.bound[0], A.bound[1], A.bound[2]);
     bound.hi = mk3(A.bound[4], A.bound[5], A.bound[6]);

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_initTrace(RayAoS* rays, PoiAoS* pois, c
             bool have = true;
             float cx, cy;
             if (rpp > 1) {
-                const uint32_t side = f2u(cl_sqrt((float)rpp));
+                const uint32_t side = f2u_uniform(cl_sqrt((float)rpp));
                 have = smp < side * side;             // rpp that is not a square: the k x k loops leave the tail rays unwritten
                 const float delta = 1.0f / (float)side;
                 const uint32_t i = side ? smp / side : 0u, j = smp - i * side;

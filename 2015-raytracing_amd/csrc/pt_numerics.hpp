@@ -81,15 +81,22 @@ PT_DEV float cl_sqrt(float x) {
 }
 PT_DEV float cl_mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// float -> int the way v_cvt_i32_f32 does it (truncate, saturate, NaN -> 0), spelled
-// out so the compiler cannot treat an out-of-range input as poison.
+// float -> int: v_cvt_i32_f32 / v_cvt_u32_f32 themselves (truncate, saturate, NaN -> 0: the contract).  As inline assembly, because a C cast
+// of an out-of-range value is poison to the compiler and the spelled-out version (three compares and selects around the cast) cost eight
+// instructions where the hardware needs one.
 PT_DEV int32_t f2i(float f) {
-    if (f != f) return 0;
-    if (f >= 2147483648.0f) return INT32_MAX;
-    if (f <= -2147483648.0f) return INT32_MIN;
-    return (int32_t)f;
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
 }
 PT_DEV uint32_t f2u(float f) {
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+// The same conversion spelled in C, for WAVE-UNIFORM values (image size, lens grid side: kernel arguments): the result stays a scalar the
+// compiler can branch and loop on without exec masks (an asm result is a per-lane value to it).
+PT_DEV uint32_t f2u_uniform(float f) {
     if (f != f) return 0u;
     if (f >= 4294967296.0f) return UINT32_MAX;
     if (f <= 0.0f) return 0u;
