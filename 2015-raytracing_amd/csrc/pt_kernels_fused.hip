@@ -419,7 +419,10 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
 #define PT_STAGE_TABLES 1
 #endif
 #ifndef PT_FUSED_WAVES_GRIDS
-#define PT_FUSED_WAVES_GRIDS 5   // with the shared-test walk (pt_trace_coop.hpp; 27.5 KB of LDS per block on cornell_teapot3 -> 5 blocks per CU anyway): 6 -> 48.8 ms, 5 -> 43.0, 4 -> 48.1
+#define PT_FUSED_WAVES_GRIDS 6   // the grid walk is latency-bound: it wants waves.  Round 3, cornell_teapot3 1080p x 16: 4 waves per SIMD 38.2 ms, 5 (96 VGPRs, no
+                                // scratch) 31.6, 6 (80 VGPRs, 18 spilled around the walks, 64 B of scratch) 29.3 -- 6 needs a block's LDS within 26 880 B (six
+                                // blocks per CU at the 1280-byte granule), which it is since the owner's ray travels by ds_bpermute (pt_trace_coop.hpp)
+                                // (round 2, at five blocks per CU whatever this said: 6 -> 48.8 ms, 5 -> 43.0, 4 -> 48.1)
 #endif
 template <bool FAST, int GRIDS>
 __global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES)) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words) {

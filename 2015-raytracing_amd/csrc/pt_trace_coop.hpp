@@ -32,7 +32,14 @@ namespace pt {
 // the start of the dynamic segment (the staged cell-offset tables follow: launch_fused).
 // The owner's maxt, cell window and pair base are NOT rows: they reach a tester through ds_bpermute from the owner's registers (four
 // rows = 4 KB of LDS per block less, and cornell_teapot3 853 -> 859 Msamples/s).
+#ifndef PT_COOP_RAY_BPERMUTE
+#define PT_COOP_RAY_BPERMUTE 1   // the owner's ray reaches a tester by ds_bpermute from the owner's registers too: six rows (6 KB per block) less
+#endif
+#if PT_COOP_RAY_BPERMUTE
+enum { CW_OWN = 0, CW_T, CW_BETA, CW_GAMMA, CW_KEY /* two rows: 64 x u64 */, CW_ROWS = 6 };
+#else
 enum { CW_OX = 0, CW_OY, CW_OZ, CW_DX, CW_DY, CW_DZ, CW_OWN, CW_T, CW_BETA, CW_GAMMA, CW_KEY /* two rows: 64 x u64 */, CW_ROWS = 12 };
+#endif
 constexpr uint32_t kCoopWordsPerBlock = 4u * CW_ROWS * 64u;
 
 template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
@@ -120,8 +127,10 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
         cmin = bh.tmin;
         cmax = cl_min(cl_min(tnx, tny), tnz);
         cell_range<LDS_TABLES>(S, off, __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx, i, end);
+#if !PT_COOP_RAY_BPERMUTE
         CW_MINE(CW_OX) = __float_as_uint(ray.o.x); CW_MINE(CW_OY) = __float_as_uint(ray.o.y); CW_MINE(CW_OZ) = __float_as_uint(ray.o.z);
         CW_MINE(CW_DX) = __float_as_uint(ray.d.x); CW_MINE(CW_DY) = __float_as_uint(ray.d.y); CW_MINE(CW_DZ) = __float_as_uint(ray.d.z);
+#endif
     }
     keys[lane] = kNone;
     // one past the last slot of the set: a (ray, primitive) pair is only ever formed below it (a table that lies cannot send a load astray)
@@ -175,12 +184,19 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
             const float ocmin = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(cmin)));
             const float ocmax = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(cmax)));
             const uint32_t oibx = (uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)(i - excl));
+#if PT_COOP_RAY_BPERMUTE
+            auto pull = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(v))); };
+            const f3 ro = mk3(pull(ray.o.x), pull(ray.o.y), pull(ray.o.z));
+            const f3 rd = mk3(pull(ray.d.x), pull(ray.d.y), pull(ray.d.z));
+#endif
             if (p < total && mark != 0u) {
                 const uint32_t o = mark - 1u;
                 const uint32_t prim = oibx + p;
                 if (prim < nslots) {
+#if !PT_COOP_RAY_BPERMUTE
                     const f3 ro = mk3(__uint_as_float(CW_OF(CW_OX, o)), __uint_as_float(CW_OF(CW_OY, o)), __uint_as_float(CW_OF(CW_OZ, o)));
                     const f3 rd = mk3(__uint_as_float(CW_OF(CW_DX, o)), __uint_as_float(CW_OF(CW_DY, o)), __uint_as_float(CW_OF(CW_DZ, o)));
+#endif
                     const float4* __restrict__ q = prims + 3u * (size_t)prim;
                     float tt, bb, gg;
                     if (tri_test<TRI_A10, FAST>(ro, rd, ocmin, ocmax, q[0], q[1], q[2], tt, bb, gg) && tt < omax) {
