@@ -7,8 +7,8 @@
 // Here the walk alternates two wave-wide phases:
 //   A  every live lane steps its own DDA through EMPTY cells until it stands in a cell that holds primitives (or has left the grid);
 //   B  the (ray, primitive) pairs of ALL those cells -- lane L contributes end_L - i_L of them -- are laid out back to back
-//      (a wave prefix sum) and tested 64 at a time by whichever lanes are free, each tester fetching "its" ray from the owner's
-//      record in LDS and the owner's maxt / cell window by ds_bpermute.  Hits go back to the owner through one LDS atomic: a 64-bit minimum over (t, primitive index).
+//      (a wave prefix sum) and tested 64 at a time by whichever lanes are free, each tester fetching "its" ray, maxt and cell window
+//      from the owner's REGISTERS by ds_bpermute.  Hits go back to the owner through one LDS atomic: a 64-bit minimum over (t, primitive index).
 // A lane's ray meets exactly the cells, and in each cell exactly the primitives with exactly the [cmin, cmax] windows, of the
 // reference's nested loops (A10 code.cl:937-1070, 1195-1321); only WHO evaluates a test and in which order changes.  Order does not
 // matter: inside a cell the reference keeps the hit with the smallest t, the first one among equals (strict <, code.cl:1017-1026) --
@@ -28,10 +28,11 @@
 
 namespace pt {
 
-// One wave's exchange area in the block's dynamic LDS: CW_ROWS rows of 64 words, [row][lane]; 3 KB per wave, 12 KB per block, at
+// One wave's exchange area in the block's dynamic LDS: CW_ROWS rows of 64 words, [row][lane]; 1.5 KB per wave, 6 KB per block, at
 // the start of the dynamic segment (the staged cell-offset tables follow: launch_fused).
 // The owner's maxt, cell window and pair base are NOT rows: they reach a tester through ds_bpermute from the owner's registers (four
-// rows = 4 KB of LDS per block less, and cornell_teapot3 853 -> 859 Msamples/s).
+// rows = 4 KB of LDS per block less, and cornell_teapot3 853 -> 859 Msamples/s) -- and since round 3 neither is its ray (six rows more:
+// what lets six blocks share a CU's LDS, pt_kernels_fused.hip PT_FUSED_WAVES_GRIDS).
 #ifndef PT_COOP_RAY_BPERMUTE
 #define PT_COOP_RAY_BPERMUTE 1   // the owner's ray reaches a tester by ds_bpermute from the owner's registers too: six rows (6 KB per block) less
 #endif
