@@ -23,6 +23,7 @@
 // {p0, e1 = p1-p0, e2 = p2-p0, n = cross(e2,e1)} -- the ray-independent head of
 // Moeller-Trumbore (A10 code.cl:252-256), computed once with the same fp32 operations, so
 // every value that reaches a ray-dependent operation has the bits it has in the reference.
+#include <stdlib.h>
 #include "pt_trace_coop.hpp"
 
 #ifndef PT_SKIP_DARK_SHADOWS
@@ -424,8 +425,11 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
                                 // blocks per CU at the 1280-byte granule), which it is since the owner's ray travels by ds_bpermute (pt_trace_coop.hpp)
                                 // (round 2, at five blocks per CU whatever this said: 6 -> 48.8 ms, 5 -> 43.0, 4 -> 48.1)
 #endif
-template <bool FAST, int GRIDS>
-__global__ void __launch_bounds__(256, GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES)) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words) {
+// WAVES != 0: an occupancy variant of the optimistic grid kernels.  PT_FUSED_WAVES_GRIDS waves per SIMD only exist while a block's LDS lets as
+// many blocks share a CU (26 880 B at six); a scene with bigger cell tables gets five blocks at best, and for it the 96-register build --
+// no scratch -- is the better kernel: launch_fused picks by the bytes it is about to ask for.
+template <bool FAST, int GRIDS, int WAVES = 0>
+__global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_GRIDS : (FAST ? PT_FUSED_WAVES_FAST : PT_FUSED_WAVES))) k_fusedPass(const FusedArgs A, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words) {
     const uint64_t n_local = (uint64_t)A.nrows * A.width * A.rpp;
     stage_block<FAST, GRIDS>(A);
     // Exact kernel in redo mode (`redo_mask`: the bits the optimistic kernel set): one thread per 32-sample word, a loop over its
@@ -574,7 +578,14 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
     const size_t lds_tri = tri_words ? (size_t)(tri_base4 - tri_base + tri_words) * 4u : 0u;
     const size_t lds2 = (size_t)kCoopWordsPerBlock * 4u + lds_tri, lds = (size_t)kCoopWordsPerBlock * 4u + (staged ? (size_t)used * 4u : 0u) + lds_tri;
     if (fast) {
-        if (grids && staged) hipLaunchKernelGGL((k_fusedPass<true, 1>), grid, dim3(256), lds, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
+        // LDS is handed out in 1280-byte granules, 128 of them per CU: the blocks per CU this launch can have, and the waves per SIMD worth compiling for
+        static const int force_waves = [] { const char* e = getenv("MIRT_GRID_WAVES"); return e ? atoi(e) : 0; }();   // A/B and test switch
+        const size_t fixed = sizeof(float) * ((size_t)PT_PARK_WORDS(1) * 256u + kLensTab);   // the grid kernels' static LDS: parked state, lens table
+        const size_t want = grids && staged ? lds : lds2, granules = (want + fixed + 1279u) / 1280u;
+        const bool five = force_waves ? force_waves == 5 : (granules ? 128u / granules : 8u) < (unsigned)PT_FUSED_WAVES_GRIDS;
+        if (grids && staged && five) hipLaunchKernelGGL((k_fusedPass<true, 1, 5>), grid, dim3(256), lds, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
+        else if (grids && staged) hipLaunchKernelGGL((k_fusedPass<true, 1>), grid, dim3(256), lds, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
+        else if (grids && five) hipLaunchKernelGGL((k_fusedPass<true, 2, 5>), grid, dim3(256), lds2, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
         else if (grids) hipLaunchKernelGGL((k_fusedPass<true, 2>), grid, dim3(256), lds2, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
         else hipLaunchKernelGGL((k_fusedPass<true, 0>), grid, dim3(256), lds_tri, s, b, defer_mask, (const uint32_t*)nullptr, 0u);
     } else {
