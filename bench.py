@@ -268,13 +268,15 @@ def main():
     flops = None if fps_table is None else fps_table.get(args.bounces, fps_table[5] * (1 + args.bounces) / 6.0)
     valu_tf = (flops or 0.0) * local_samples / (fused_ms * 1e-3) / 1e12
     has_grids = any(m["nslabs"] > 1 for m in sc.d.get("meshes", [])) or sc.d.get("n_slabs", 1) > 1
-    kernel_name = "pt::k_fusedPass<true,1>" if has_grids else "pt::k_fusedPass<true,0>"   # <optimistic, grids: 0 none / 1 tables in LDS / 2 in memory>
+    # <optimistic, grids: 0 none / 1 tables in LDS / 2 in memory, waves: 0 the default build / 5 the grid kernels' 5-wave build>; matched as a prefix
+    kernel_name = "pt::k_fusedPass<true,1," if has_grids else "pt::k_fusedPass<true,0,"
     hbm_gbs = BYTES_PER_SAMPLE_FUSED * local_samples / (fused_ms * 1e-3) / 1e9
 
     # counters: only what a named rocprofv3 summary of this build and workload holds (FETCH_SIZE / WRITE_SIZE in KiB, separate passes;
     # gfx950 halves FETCH_SIZE on wide coalesced reads: MI355X_MICROARCH.md)
     workload_key = f"{args.scene}_{sc.width}x{sc.height}_r{sc.rpp}_b{args.bounces}_n{world}"
     pmc_path, pmc = find_pmc_summary(args.pmc_summary, workload_key, kernel_name) if rank == 0 else (None, "rank != 0")
+    kernel_name += "*>" if has_grids else "0>"   # the name as rocprofv3 prints it, spaces aside (the grid kernels come in two occupancy builds)
     cnt = (lambda c: pmc[c]["mean_per_dispatch"] if c in pmc else None) if pmc_path else (lambda c: None)
     fetch, write = cnt("FETCH_SIZE"), cnt("WRITE_SIZE")
     traffic = (fetch * 2 + write) * 1024.0 if fetch is not None and write is not None else None
