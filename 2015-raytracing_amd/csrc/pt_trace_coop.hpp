@@ -33,6 +33,9 @@ namespace pt {
 // The owner's maxt, cell window and pair base are NOT rows: they reach a tester through ds_bpermute from the owner's registers (four
 // rows = 4 KB of LDS per block less, and cornell_teapot3 853 -> 859 Msamples/s) -- and since round 3 neither is its ray (six rows more:
 // what lets six blocks share a CU's LDS, pt_kernels_fused.hip PT_FUSED_WAVES_GRIDS).
+#ifndef PT_COOP_RUNNING_CELL
+#define PT_COOP_RUNNING_CELL 1   // phase A carries the cell index and the three slab indices (packed) along instead of re-deriving the index per step
+#endif
 #ifndef PT_COOP_RAY_BPERMUTE
 #define PT_COOP_RAY_BPERMUTE 1   // the owner's ray reaches a tester by ds_bpermute from the owner's registers too: six rows (6 KB per block) less
 #endif
@@ -110,8 +113,13 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
 
     float tnx = 0.0f, tny = 0.0f, tnz = 0.0f, dtx = 0.0f, dty = 0.0f, dtz = 0.0f;
     int sx = 0, sy = 0, sz = 0;
-    const int nn = (int)S.n;
     const uint32_t zs = S.n * S.n, ys = S.n;   // n <= 1024 (check_grid): 24-bit multiplies are exact
+#if PT_COOP_RUNNING_CELL
+    const uint32_t last = S.n - 1u;
+    uint32_t cell = 0u, pk = 0u;
+#else
+    const int nn = (int)S.n;
+#endif
     const bool fwx = ray.d.x >= 0, fwy = ray.d.y >= 0, fwz = ray.d.z >= 0;   // code.cl:701-705: d >= 0 ? +1, n : -1, -1
     float cmin = 0.0f, cmax = 0.0f;
     uint32_t i = 0u, end = 0u;
@@ -127,7 +135,13 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
         sx = ax.slab; sy = ay.slab; sz = az.slab;
         cmin = bh.tmin;
         cmax = cl_min(cl_min(tnx, tny), tnz);
+#if PT_COOP_RUNNING_CELL
+        cell = __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx;
+        pk = (uint32_t)sx | (uint32_t)sy << 10 | (uint32_t)sz << 20;
+        cell_range<LDS_TABLES>(S, off, cell, i, end);
+#else
         cell_range<LDS_TABLES>(S, off, __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx, i, end);
+#endif
 #if !PT_COOP_RAY_BPERMUTE
         CW_MINE(CW_OX) = __float_as_uint(ray.o.x); CW_MINE(CW_OY) = __float_as_uint(ray.o.y); CW_MINE(CW_OZ) = __float_as_uint(ray.o.z);
         CW_MINE(CW_DX) = __float_as_uint(ray.d.x); CW_MINE(CW_DY) = __float_as_uint(ray.d.y); CW_MINE(CW_DZ) = __float_as_uint(ray.d.z);
@@ -147,6 +161,26 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
         while (alive && i == end) {
             const float t = cmax;
             bool out;
+#if PT_COOP_RUNNING_CELL
+            // the slab indices packed ten bits each (0 <= slab < n <= 1024 while the ray is inside) and the cell index carried along:
+            // "the step leaves the grid" (code.cl:701-705's limit, n or -1) is "the slab stepped FROM is n - 1 or 0"
+            if (t == tnx) {
+                tnx += dtx;
+                out = t >= bh.tmax || (pk & 1023u) == (fwx ? last : 0u);
+                pk += fwx ? 1u : ~0u;
+                cell += fwx ? 1u : ~0u;
+            } else if (t == tny) {
+                tny += dty;
+                out = t >= bh.tmax || ((pk >> 10) & 1023u) == (fwy ? last : 0u);
+                pk += fwy ? 1u << 10 : 0u - (1u << 10);
+                cell += fwy ? ys : 0u - ys;
+            } else {
+                tnz += dtz;
+                out = t >= bh.tmax || (pk >> 20) == (fwz ? last : 0u);
+                pk += fwz ? 1u << 20 : 0u - (1u << 20);
+                cell += fwz ? zs : 0u - zs;
+            }
+#else
             if (t == tnx) {
                 tnx += dtx;
                 sx += fwx ? 1 : -1;
@@ -160,12 +194,17 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
                 sz += fwz ? 1 : -1;
                 out = t >= bh.tmax || sz == (fwz ? nn : -1);
             }
+#endif
             // ... or the cell starts at or beyond the ray's end: a hit needs cmin <= t < maxt, and cmin only grows from here
             // (the reference walks on to the grid's far side rejecting every hit; nothing it computes there survives)
             if (out || t >= ray.maxt) { alive = false; break; }
             cmin = t;
             cmax = cl_min(cl_min(tnx, tny), tnz);
+#if PT_COOP_RUNNING_CELL
+            cell_range<LDS_TABLES>(S, off, cell, i, end);
+#else
             cell_range<LDS_TABLES>(S, off, __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx, i, end);
+#endif
         }
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         // ---- phase B: every pair (owner lane, primitive of its cell), 64 at a time
