@@ -289,6 +289,69 @@ def _regrid_mesh(m, n):
     return dict(m, nslabs=n, box=off.tolist(), pos=pos[order].ravel().tolist(), normal=nor[order].ravel().tolist())
 
 
+def _sparse_grid(tri, bounds6, n):
+    """expected_grid (tests/test_grid_build.py) without its n^3 Python lists: the same cell ranges per triangle, a stable sort by cell."""
+    tri = np.asarray(tri, np.float64).reshape(-1, 3, 3)
+    bmin = np.asarray(bounds6[:3], np.float64)
+    w = (np.asarray(bounds6[3:], np.float64) - bmin) / n
+    a = np.maximum(np.floor((tri.min(axis=1) - bmin) / w), 0).astype(np.int64)
+    b = np.minimum(np.floor((tri.max(axis=1) - bmin) / w), n - 1).astype(np.int64)
+    cells, ids = [], []
+    for i in range(len(tri)):
+        if (a[i] > b[i]).any():
+            continue
+        z, y, x = np.meshgrid(*(np.arange(a[i][k], b[i][k] + 1) for k in (2, 1, 0)), indexing="ij")
+        c = ((z * n + y) * n + x).ravel()
+        cells.append(c)
+        ids.append(np.full(c.size, i, np.int64))
+    cells, ids = np.concatenate(cells), np.concatenate(ids)
+    order = np.lexsort((ids, cells))
+    off = np.zeros(n ** 3 + 1, np.uint32)
+    off[1:] = np.cumsum(np.bincount(cells, minlength=n ** 3))
+    return off, ids[order].astype(np.uint32)
+
+
+def test_small_triangles_in_a_300_cube_grid(ctx, pkg):
+    """Slab indices beyond eight bits: 300 small triangles in a 300^3 grid (27 M cells, a 108 MB offset table read from memory) in place of
+    cornell_teapot3's box.  The shared-test walk packs its three slab indices ten bits each and carries the cell index along
+    (pt_trace_coop.hpp): rays cross up to 900 cells here.  Fused pass (both modes) and kernel-by-kernel path against the CPU oracle."""
+    from raytracing_amd.pyhost import render
+    fx, sc0 = load_fixture("cornell_teapot3_32x24_r4")
+    m = sc0.d["meshes"][1]
+    b = np.asarray(m["bounds"], np.float64)
+    rng = np.random.default_rng(300)
+    c = b[:3] + (b[4:7] - b[:3]) * rng.uniform(0.05, 0.95, (300, 1, 3))
+    tri = (c + rng.uniform(-0.05, 0.05, (300, 3, 3))).astype(np.float32)
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(np.float64)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    pos4 = np.concatenate([tri, np.ones((300, 3, 1), np.float32)], axis=2).reshape(300, 12)
+    nor4 = np.concatenate([np.repeat(nrm[:, None, :], 3, axis=1), np.zeros((300, 3, 1), np.float32)], axis=2).reshape(300, 12)
+    n = 300
+    off, order = _sparse_grid(tri.astype(np.float64).reshape(-1, 9), [b[0], b[1], b[2], b[4], b[5], b[6]], n)
+    assert 100_000 < order.size < 3_000_000
+    mesh = dict(m, nslabs=n, box=off, pos=pos4[order].ravel(), normal=nor4[order].ravel())
+    sc = _variant(sc0, width=96, height=54, rays_per_pixel=4, meshes=[sc0.d["meshes"][0], mesh])
+    seeds = A.make_seeds(sc.total_rays, seed_base=n)
+    orc = A.load_oracle()
+    st = A.PassState(sc, seeds)
+    A.run_pass(orc, sc, st)
+    assert (st.pois["matId"] == m["matid"]).mean() > 0.005   # some paths end on the small triangles
+    for exact_only in (False, True):
+        ctx.set_exact_only(exact_only)
+        fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+        fr.execute_render()
+        assert np.array_equal(bits(fr.acu.read(np.float32).reshape(-1, 4)), bits(st.acu)), f"fused, exact_only={exact_only}"
+        assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
+        fr.release()
+    ctx.set_exact_only(False)
+    gr = render.GranularRenderer(ctx, sc, seeds=seeds)
+    gr.execute_render()
+    got = snapshot(gr)
+    assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds), "granular"
+    assert np.array_equal(got["pois"]["matId"], st.pois["matId"])
+    gr.release()
+
+
 @pytest.mark.parametrize("n", [2, 17, 24])
 def test_teapot_at_other_grid_resolutions(ctx, pkg, n):
     """cornell_teapot3 with its teapot re-binned: n = 2 puts hundreds of triangles in a cell (the shared-test walk lays one cell out over
