@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
 // sweep evaluates that plane once and shifts its verdict in for both (cornell.xml: 12 triangles, 7 planes).  A run never crosses a chunk
 // of 32 records (one candidate word).  Entry: {n, k} {G, H, run, 0} with the margin constants of the plane window,
 // M = G |o|_1 + H = 2^-17 |e1|_1 |e2|_1 (|o|_1 + |p0|_1), each product rounded up, H at least 2^-56; a run takes the larger G and H of
-// its records (a wider margin is always safe).  Serial: at most 128 records, once per buffer content.
+// its records (a wider margin is always safe); the header also carries each chunk's largest G and H, which is what the sweep uses for every
+// plane of the chunk (PT_SWEEP_UNIFORM_MARGIN).  Serial: at most 128 records, once per buffer content.
 __global__ void __launch_bounds__(64) k_planeRuns(const float4* prep, uint32_t count, float4* planes) {
     if (threadIdx.x != 0u || blockIdx.x != 0u) return;
     uint32_t* hdr = (uint32_t*)planes;
@@ -112,9 +113,11 @@ __global__ void __launch_bounds__(64) k_planeRuns(const float4* prep, uint32_t c
                __float_as_uint(x.w) == __float_as_uint(y.w);
     };
     uint32_t np = 0;
+    for (uint32_t c = 8u; c < 16u; ++c) hdr[c] = 0u;
     for (uint32_t c = 0; c < 4u; ++c) {
         const uint32_t lo = c * 32u, hi = lo + 32u < count ? lo + 32u : count;
         hdr[4u + c] = np;
+        float gmax = 0.0f, hmax = 0.0f;
         for (uint32_t i = lo; i < hi;) {
             float4 a, b;
             make(i, a, b);
@@ -125,15 +128,16 @@ __global__ void __launch_bounds__(64) k_planeRuns(const float4* prep, uint32_t c
                 if (same(a, a2)) { run = 2u; b.x = __builtin_fmaxf(b.x, b2.x); b.y = __builtin_fmaxf(b.y, b2.y); }
             }
             b.z = __uint_as_float(run);
+            gmax = __builtin_fmaxf(gmax, b.x); hmax = __builtin_fmaxf(hmax, b.y);
             ent[2u * np] = a;
             ent[2u * np + 1u] = b;
             ++np;
             i += run;
         }
         hdr[c] = lo < count ? np - hdr[4u + c] : 0u;
+        hdr[8u + c] = __float_as_uint(gmax); hdr[12u + c] = __float_as_uint(hmax);   // the chunk's largest margin constants (PT_SWEEP_UNIFORM_MARGIN)
         if (np & 1u) { ent[2u * np] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ent[2u * np + 1u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ++np; }   // run = 0: shifts nothing in
     }
-    for (uint32_t c = 8u; c < 16u; ++c) hdr[c] = 0u;
 }
 
 // Cold per-ray state parked in LDS instead of registers: the accumulator (touched once per shading event) and the

@@ -40,7 +40,7 @@ constexpr uint32_t kLdsTriMax = 96;       // single-cell triangle sets staged in
 struct GridArgs {            // one cell-sorted primitive set, device pointers
     const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per PREPARED triangle (launch_prepTriangles)
     const void* pnorm;       // triangles, at most kLdsTriMax records: the candidate sweep's PLANE list behind the records and group spheres
-                             // (prepared_planes_offset; k_planeRuns writes it): a 64-byte header {planes[4], first[4]} per chunk of 32 records, then
+                             // (prepared_planes_offset; k_planeRuns writes it): a 64-byte header {planes[4], first[4], Gmax[4], Hmax[4]} per chunk of 32 records, then
                              // 32 bytes per plane {n.xyz, k = p0 . n, G, H, run, 0}: n = cross(e2, e1), the two constants of the plane-window margin
                              // M = G |o|_1 + H, and how many CONSECUTIVE records (1 or 2: the halves of a quad) lie in it bit for bit.  Read by scalar
                              // loads in the sweep (pt_trace.hpp trace_cell1).  Null: no list (the set runs the wave-uniform loop)

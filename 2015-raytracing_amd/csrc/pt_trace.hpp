@@ -50,6 +50,10 @@ enum TriRule { TRI_A10 = 0, TRI_A07 = 1, TRI_A04 = 2 };
 #ifndef PT_SPHERE_WAVE_SKIP
 #define PT_SPHERE_WAVE_SKIP 1
 #endif
+#ifndef PT_SWEEP_UNIFORM_MARGIN
+#define PT_SWEEP_UNIFORM_MARGIN 1   // the sweep's plane-window margin once per chunk of 32 records, from the chunk's largest constants (the header carries them),
+                                    // instead of one fma per plane from each plane's own: headline kernel 106.8 -> 104.8 ms
+#endif
 #ifndef PT_LANE_FILTER
 #define PT_LANE_FILTER 1   // the candidate sweep of trace_cell1 also drops triangles whose plane the ray meets outside its window
 #endif
@@ -373,7 +377,7 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     const uint32_t end = __builtin_amdgcn_readfirstlane(ldc_u32(S.off, 1));
     bool done = false;
     if (LANES && KIND == TRIANGLES && FAST && RULE == TRI_A10 && S.lds_off != kNoLds && begin == 0u) {
-        // the sweep's plane list (k_planeRuns): a 64-byte header {planes[4], first[4]} per chunk of 32 records, then one entry per run of
+        // the sweep's plane list (k_planeRuns): a 64-byte header {planes[4], first[4], Gmax[4], Hmax[4]} (one slot per chunk of 32 records), then one entry per run of
         // consecutive records in one plane: {n.xyz, k = p0.n} {G, H, run, 0}; two entries per s_load_dwordx16
         const pt_v16f PT_CONST_AS* pn = (const pt_v16f PT_CONST_AS*)((const char PT_CONST_AS*)S.pnorm + 64);
         const uint32_t lds_bytes = S.lds_off * 4u;
@@ -384,7 +388,8 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         // Both evaluations stay within 14 u E (|o|_1 + |p0|_1) of each other (u = 2^-24, E = |e1|_1 |e2|_1: the rounding of s, of the two
         // cross products, of the dot products, of n and of k, term by term); the sweep allows M = 2^-17 E (|o|_1 + |p0|_1), nine times
         // that, never less than 2^-56, and widens the window by 2^-20 relative, which also covers the three roundings between the
-        // reference's numerator and its t and those of the two tests below.  With div > 0:
+        // reference's numerator and its t and those of the two tests below (PT_SWEEP_UNIFORM_MARGIN: every plane of a chunk gets the chunk's LARGEST
+        // G and H -- a wider margin keeps more, never less).  With div > 0:
         //   -sn - M > hi+ * div,  hi+ = max(min(cmax, maxt) * (1 + 2^-20), 2^-100)   =>   the reference's t > min(cmax, maxt): no hit
         //   -sn + M < lo- * div,  lo- = cmin * (1 - 2^-20)                            =>   the reference's t < cmin, and at least
         //        2^-57 / 2^82 in magnitude when cmin = 0 (no underflow to a -0 that would pass t >= 0): no hit
@@ -399,6 +404,9 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         for (uint32_t c0 = 0u; c0 < end; c0 += 32u) {
             const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u;
             const uint32_t planes = ldc_u32(S.pnorm, c0 >> 5), first = ldc_u32(S.pnorm, 4u + (c0 >> 5));
+#if PT_LANE_FILTER && PT_SWEEP_UNIFORM_MARGIN
+            const float Mu = cl_fma(__uint_as_float(ldc_u32(S.pnorm, 8u + (c0 >> 5))), o1, __uint_as_float(ldc_u32(S.pnorm, 12u + (c0 >> 5))));
+#endif
             uint32_t neg = 0u;
             for (uint32_t g = 0; g < (planes + 1u) >> 1; ++g) {
                 const pt_v16f v = pn[(first >> 1) + g];
@@ -410,7 +418,11 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
                     const float div = dot3(mk3(v[8 * k], v[8 * k + 1], v[8 * k + 2]), ray.d);
 #if PT_LANE_FILTER
                     const float sn = cl_fma(v[8 * k + 2], ray.o.z, cl_fma(v[8 * k + 1], ray.o.y, cl_fma(v[8 * k], ray.o.x, -v[8 * k + 3])));
+#if PT_SWEEP_UNIFORM_MARGIN
+                    const float M = Mu;   // the largest margin of the chunk for every plane of it: wider is always safe
+#else
                     const float M = cl_fma(v[8 * k + 4], o1, v[8 * k + 5]);
+#endif
                     const float c = cl_fma(hi_p, div, sn + M), a = cl_fma(lo_m, div, sn - M);
                     const float w = __builtin_fminf(__builtin_fminf(div, c), -a);   // one v_min3_f32; negative: not a candidate
 #else

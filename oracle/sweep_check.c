@@ -10,7 +10,9 @@
  * the window edges cmin / cmax / maxt placed on the reference's own t for that pair and a few ulps either side, geometry scaled over
  * forty octaves, needle triangles, near-parallel rays -- and counts the violations (dropped by the sweep, accepted by the reference).
  * tests/test_sweep_filter.py asserts the count is zero and that the sweep still drops most of what the reference rejects (it is a
- * filter, not a constant `true`).  The margin's derivation is in pt_trace.hpp; this is its empirical side, runnable without a GPU. */
+ * filter, not a constant `true`).  The margin's derivation is in pt_trace.hpp; this is its empirical side, runnable without a GPU.
+ * The margin checked is each triangle's OWN (G, H); the kernel gives every plane of a 32-record chunk the chunk's largest pair
+ * (PT_SWEEP_UNIFORM_MARGIN), which keeps a superset of what is kept here: the check is on the tightest margin the product can use. */
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
