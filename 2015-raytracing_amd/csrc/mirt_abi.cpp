@@ -79,6 +79,8 @@ struct mirt_ctx {
     void* defer = nullptr;        // optimistic pass: [count, cursor, pad, pad | mask words...]
     size_t defer_bytes = 0;
     uint32_t defer_words = 0;     // mask words the last mirt_render_pass used (0: it ran the exact kernel only)
+    uint32_t defer_unit = 1;      // samples per mask bit: 1, or 256 when that pass resolved its pixels itself (a bit per block)
+    bool inpass_resolve = true;   // a frame's first pass writes pixel / radiance itself where it can (MIRT_INPASS_RESOLVE=0: always the separate copyToPixel)
     int force_exact = 0;          // mirt_ctx_set_exact_only: 1 = skip the optimistic kernel, run every sample through the exact one
     bool profiling = false;       // per-kernel events inside mirt_render_pass
     hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
@@ -127,6 +129,7 @@ struct mirt_buf {
     uint64_t off_version = 0;
     uint32_t off_n = 0;
     uint32_t off_last = 0;
+    uint32_t off_first = 0;       // off[0]: where the first cell's list starts (0 in every table a grid builder makes)
     uint32_t prep_count = 0;   // records in `prep` (the group spheres sit at record index prep_count)
     // prepared-triangle copy of a position buffer (fused path), rebuilt when the contents change
     void* prep = nullptr;
@@ -256,6 +259,7 @@ int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const
         off->off_version = off->version;
         off->off_n = n;
         off->off_last = h[cells];
+        off->off_first = h[0];
     }
     pin(ctx, off, true);
     const uint64_t count = off->off_last;
@@ -389,6 +393,7 @@ static int create_ctx(int device, mirt_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, MIRT_E_DEVICE, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
+    if (const char* f = getenv("MIRT_INPASS_RESOLVE")) c->inpass_resolve = atoi(f) != 0;   // A/B and test switch
     if (const char* f = getenv("MIRT_FUSION")) c->fusion = atoi(f) >= 2 ? 2 : 0;   // same as mirt_ctx_set_fusion: for hosts that cannot be edited at all
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
@@ -1260,6 +1265,7 @@ static int fill_grid(mirt_ctx* ctx, const char* what, const mirt_grid* g, bool t
     // the walk's wave-uniform quotients, once, in the arithmetic the kernel would use: fp32, correctly rounded
     o->walk_ok = 1;
     o->nslots = g->cell_offsets->off_last;   // validated by check_grid above
+    o->first_zero = g->cell_offsets->off_first == 0u;
     for (int k = 0; k < 3; ++k) {
         const float span = g->bounds[4 + k] - g->bounds[k];
         const float delta = span / (float)g->n_slabs;
@@ -1311,6 +1317,19 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     if (d->triangles && (rc = fill_grid(ctx, "triangles", d->triangles, true, true, &A.sets[A.n_sets++]))) return rc;
     for (uint32_t m = 0; m < d->n_meshes; ++m)
         if ((rc = fill_grid(ctx, "mesh", &d->meshes[m], true, false, &A.sets[A.n_sets++]))) return rc;
+    // one prepared copy per position buffer, laid out for ONE record count: two sets of a pass that share a buffer with different counts would have
+    // the second fill_grid re-lay the copy the first set's pointers describe
+    {
+        const mirt_grid* gs[2 + MIRT_MAX_MESHES];
+        uint32_t ng = 0;
+        if (d->triangles) gs[ng++] = d->triangles;
+        for (uint32_t m = 0; m < d->n_meshes; ++m) gs[ng++] = &d->meshes[m];
+        for (uint32_t i = 0; i < ng; ++i)
+            for (uint32_t j = i + 1; j < ng; ++j)
+                if (gs[i]->prims == gs[j]->prims && gs[i]->cell_offsets->off_last != gs[j]->cell_offsets->off_last)
+                    return fail(ctx, MIRT_E_ARG, "mirt_render_pass: two triangle sets share a position buffer but hold %u and %u slots (one prepared copy per buffer: "
+                                                 "give each set its own buffer)", gs[i]->cell_offsets->off_last, gs[j]->cell_offsets->off_last);
+    }
     for (uint32_t l = 0; l < d->n_lights; ++l) {
         memcpy(A.lights[l].shadow, d->lights[l].shadow, 64);
         memcpy(A.lights[l].scene, d->lights[l].scene, 64);
@@ -1320,11 +1339,24 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     A.material = d->material->ptr;
     A.nmat = (uint32_t)(d->material->bytes / 16);
     if ((rc = need(ctx, "seeds", d->seeds, nrays * 4))) return rc;
-    if ((rc = need(ctx, "acu", d->acu, nrays * kAcuBytes))) return rc;
+    // copyToPixel inside the pass: a frame's first pass at a ray count that puts whole pixels into a block of 256 ray ids (pt_launch.hpp
+    // fused_resolves).  Then -- and only then -- `acu` is optional: without it nothing per ray but the seed touches memory.
+    const bool resolve_in_pass = ctx->inpass_resolve && pt::fused_resolves(d->rays_per_pixel, fresh, d->pixel || d->radiance);
+    if (!d->acu && !resolve_in_pass)
+        return fail(ctx, MIRT_E_ARG, "mirt_render_pass: acu may only be null for a frame's first pass (mirt_render_first_pass) with a pixel or radiance buffer and "
+                                     "rays_per_pixel dividing 256 (here: %s, %u rays per pixel%s)", fresh ? "first pass" : "NOT a first pass", d->rays_per_pixel,
+                    d->pixel || d->radiance ? "" : ", no output buffer");
+    if (d->acu && (rc = need(ctx, "acu", d->acu, nrays * kAcuBytes))) return rc;
     A.seeds = (int32_t*)d->seeds->ptr;
-    A.acu = d->acu->ptr;
+    A.acu = d->acu ? d->acu->ptr : nullptr;
     if (d->pixel && (rc = need(ctx, "pixel", d->pixel, npix * 4))) return rc;
     if (d->radiance && (rc = need(ctx, "radiance", d->radiance, npix * 16))) return rc;
+    if (resolve_in_pass) {
+        A.resolve = 1u;
+        A.pixel = d->pixel ? d->pixel->ptr : nullptr;
+        A.radiance = d->radiance ? d->radiance->ptr : nullptr;
+        A.res_m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
+    }
 
     if (A.rpp == 1) {
         // the column streams live in seeds[0..width): only the tile that owns row 0 holds them
@@ -1339,7 +1371,8 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     if (optimistic) {
         // optimistic kernel (exact cheap divisions inside their window) + exact kernel over the samples that left the window:
         // the second launch walks the first one's bit mask on the device, so the pair is queued without a host round trip
-        const uint32_t words = (uint32_t)((nrays + 31) / 32);
+        // one bit per sample -- or, resolving in the pass, per block of 256 ray ids (pt_kernels_fused.hip)
+        const uint32_t words = resolve_in_pass ? (uint32_t)(((nrays + 255) / 256 + 31) / 32) : (uint32_t)((nrays + 31) / 32);
         const size_t need_bytes = 16 + (size_t)words * 4;
         if (ctx->defer_bytes < need_bytes) {
             NOT_WHILE_CAPTURING(ctx, "growing the deferred-sample mask");
@@ -1354,12 +1387,13 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
         pt::launch_fused(ctx->stream, A, true, mask, nullptr, 0);
         pt::launch_fused(ctx->stream, A, false, nullptr, mask, words);
         ctx->defer_words = words;
+        ctx->defer_unit = resolve_in_pass ? 256u : 1u;
     } else {
         pt::launch_fused(ctx->stream, A, false, nullptr, nullptr, 0);
         ctx->defer_words = 0;
     }
     if (ctx->profiling && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->pe[1], ctx->stream));
-    if (d->pixel || d->radiance) {
+    if (!resolve_in_pass && (d->pixel || d->radiance)) {
         const float m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
         pt::launch_copyToPixel(ctx->stream, d->pixel ? d->pixel->ptr : nullptr, A.acu, m, (uint32_t)npix, A.rpp, (uint32_t)npix,
                                d->radiance ? d->radiance->ptr : nullptr);
@@ -1367,7 +1401,7 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     if (ctx->profiling && !ctx->capturing) { HIPCHK(ctx, hipEventRecord(ctx->pe[2], ctx->stream)); ctx->pe_valid = true; }
     HIPCHK(ctx, hipGetLastError());
     d->seeds->version++;
-    d->acu->version++;
+    if (d->acu) d->acu->version++;
     return MIRT_OK;
 }
 
@@ -1411,7 +1445,7 @@ int mirt_pass_deferred(mirt_ctx* ctx, uint64_t* samples) try {
     uint32_t count = 0;
     HIPCHK(ctx, hipMemcpyAsync(&count, counters, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *samples = count;
+    *samples = (uint64_t)count * ctx->defer_unit;   // resolving in the pass the exact kernel re-runs whole blocks of 256 samples
     return MIRT_OK;
 } MIRT_CATCH("mirt_pass_deferred", return MIRT_E_DEVICE)
 
@@ -1458,6 +1492,24 @@ int mirt_zero(mirt_ctx* ctx, mirt_buf* buf) try {
     buf->version++;
     return MIRT_OK;
 } MIRT_CATCH("mirt_zero", return MIRT_E_DEVICE)
+
+int mirt_debug_prepared(mirt_ctx* ctx, mirt_buf* positions, uint32_t count, void* out, size_t bytes, size_t* total) try {
+    if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_prepared: unknown context");
+    FLUSH_PENDING(ctx);
+    NOT_WHILE_CAPTURING(ctx, "mirt_debug_prepared");
+    if (!live_has(positions) || positions->ctx != ctx) return fail(ctx, MIRT_E_HANDLE, "mirt_debug_prepared: unknown buffer");
+    int rc = need(ctx, "mirt_debug_prepared positions", positions, (uint64_t)count * 48);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_prepared(ctx, positions, count))) return rc;
+    const size_t have = pt::prepared_bytes(count);
+    if (total) *total = have;
+    if (out && bytes && positions->prep) {
+        HIPCHK(ctx, hipMemcpyAsync(out, positions->prep, bytes < have ? bytes : have, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MIRT_OK;
+} MIRT_CATCH("mirt_debug_prepared", return MIRT_E_DEVICE)
 
 int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n) try {
     if (!live_has(ctx)) return fail(nullptr, MIRT_E_HANDLE, "mirt_debug_numerics: unknown context");
@@ -1724,3 +1776,9 @@ int mirt_timer_stop_ms(mirt_ctx* ctx, float* ms) try {
 } MIRT_CATCH("mirt_timer_stop_ms", return MIRT_E_DEVICE)
 
 }  // extern "C"
+
+#if PT_COUNT
+// profiling builds only (-DPT_COUNT=1, profiles/trip_counts.py): the fused pass's wave-level trip counters (pt_trace.hpp PtCounter); not in include/mirt.h
+namespace pt { int debug_counters(unsigned long long* out, int reset); }
+extern "C" MIRT_API int mirt_debug_counters(unsigned long long* out32, int reset) { return pt::debug_counters(out32, reset); }
+#endif

@@ -87,56 +87,81 @@ __global__ void __launch_bounds__(256) k_prepTriangles(const float4* pos, float4
     }
 }
 
-// The candidate sweep's plane list of a small set (count <= kLdsTriMax; GridArgs::pnorm), from the prepared records.  One entry per RUN of
-// consecutive records whose plane is the same bit for bit -- n = cross(e2, e1) and k = p0 . n equal: the two halves of a quad -- so the
-// sweep evaluates that plane once and shifts its verdict in for both (cornell.xml: 12 triangles, 7 planes).  A run never crosses a chunk
-// of 32 records (one candidate word).  Entry: {n, k} {G, H, run, 0} with the margin constants of the plane window,
-// M = G |o|_1 + H = 2^-17 |e1|_1 |e2|_1 (|o|_1 + |p0|_1), each product rounded up, H at least 2^-56; a run takes the larger G and H of
-// its records (a wider margin is always safe); the header also carries each chunk's largest G and H, which is what the sweep uses for every
-// plane of the chunk (PT_SWEEP_UNIFORM_MARGIN).  Serial: at most 128 records, once per buffer content.
-__global__ void __launch_bounds__(64) k_planeRuns(const float4* prep, uint32_t count, float4* planes) {
+// The candidate sweep's plane list of a small set (count <= kLdsTriMax; GridArgs::pnorm), from the prepared records (layout: pt_launch.hpp
+// "plane list").  Per chunk of 32 records (one candidate word), one entry per PLANE -- every record of the chunk whose plane is the same bit
+// for bit (n = cross(e2, e1) with -0 read as +0, and k = p0 . n; for an axis plane the coordinate and the one non-zero normal component)
+// shares it through a 32-bit record mask (record c0 + j at bit 31 - j): the halves of a quad wherever they sit in the list.  A record whose
+// plane is the same with the normal REVERSED (-n, -k: the back face of a double-sided triangle) rides in the entry's second mask: the sweep
+// gets its verdict from two more fused operations instead of a whole evaluation.  AXIS planes -- n has two zero components and both edges
+// are exactly zero along the third axis, so the plane is {x_a = p0_a} exactly -- are listed per axis as {q = p0_a, n_a, mask, back mask}: the
+// sweep needs one product for n . d and two operations for n . o - k.  General planes: {n.xyz, k, mask, back mask, 0, 0}.  Entries travel
+// in 64-byte groups (one s_load_dwordx16: four axis entries or two general ones), each class padded with zero-mask entries.
+// Margin constants (pt_trace.hpp): M = G |o|_1 + H, G = 2^-17 |e1|_1 |e2|_1, H = max(G |p0|_1, 2^-56), every product rounded up; the sweep
+// uses the chunk's largest G and H for every plane of the chunk (a wider margin keeps more, never less).  Serial: at most 96 records, once per buffer content.
+__global__ void __launch_bounds__(64) k_planeList(const float4* prep, uint32_t count, uint32_t* out) {
     if (threadIdx.x != 0u || blockIdx.x != 0u) return;
-    uint32_t* hdr = (uint32_t*)planes;
-    float4* ent = planes + 4;   // the header is 64 bytes
+    uint32_t* hdr = out;
+    uint32_t* ent = out + 16;   // the header is 64 bytes; groups of 16 words follow
     const float up = 1.0000002384185791015625f;   // 1 + 2^-22: more than the rounding of the sums and products below
-    auto make = [&](uint32_t i, float4& a, float4& b) {
-        const float4 A = prep[3u * i], B = prep[3u * i + 1], C = prep[3u * i + 2];
-        const float k = (float)((double)A.x * A.w + (double)A.y * B.w + (double)A.z * C.w);
-        const float E = ((__builtin_fabsf(B.x) + __builtin_fabsf(B.y) + __builtin_fabsf(B.z)) * up) * ((__builtin_fabsf(C.x) + __builtin_fabsf(C.y) + __builtin_fabsf(C.z)) * up) * up;
-        const float G = 0x1p-17f * E;
-        const float H = __builtin_fmaxf(G * ((__builtin_fabsf(A.x) + __builtin_fabsf(A.y) + __builtin_fabsf(A.z)) * up) * up, 0x1p-56f);
-        a = make_float4(A.w, B.w, C.w, k);
-        b = make_float4(G, H, 0.0f, 0.0f);
-    };
-    auto same = [](const float4& x, const float4& y) {
-        return __float_as_uint(x.x) == __float_as_uint(y.x) && __float_as_uint(x.y) == __float_as_uint(y.y) && __float_as_uint(x.z) == __float_as_uint(y.z) &&
-               __float_as_uint(x.w) == __float_as_uint(y.w);
-    };
-    uint32_t np = 0;
-    for (uint32_t c = 8u; c < 16u; ++c) hdr[c] = 0u;
+    auto canon = [](float v) { return v == 0.0f ? 0u : __float_as_uint(v); };   // -0 -> +0 (the sign of a zero component cannot change what n . d <= 0 decides)
+    uint32_t groups = 0;   // 64-byte groups written so far
     for (uint32_t c = 0; c < 4u; ++c) {
         const uint32_t lo = c * 32u, hi = lo + 32u < count ? lo + 32u : count;
-        hdr[4u + c] = np;
+        hdr[c] = 0u; hdr[4u + c] = groups; hdr[8u + c] = 0u; hdr[12u + c] = 0u;
+        if (lo >= count) continue;
         float gmax = 0.0f, hmax = 0.0f;
-        for (uint32_t i = lo; i < hi;) {
-            float4 a, b;
-            make(i, a, b);
-            uint32_t run = 1u;
-            if (i + 1u < hi) {
-                float4 a2, b2;
-                make(i + 1u, a2, b2);
-                if (same(a, a2)) { run = 2u; b.x = __builtin_fmaxf(b.x, b2.x); b.y = __builtin_fmaxf(b.y, b2.y); }
-            }
-            b.z = __uint_as_float(run);
-            gmax = __builtin_fmaxf(gmax, b.x); hmax = __builtin_fmaxf(hmax, b.y);
-            ent[2u * np] = a;
-            ent[2u * np + 1u] = b;
-            ++np;
-            i += run;
+        // class of every record of the chunk: 0 / 1 / 2 = axis plane along x / y / z, 3 = general; and its key
+        uint32_t cls[32], key[32][4];
+        for (uint32_t i = lo; i < hi; ++i) {
+            const float4 A = prep[3u * i], B = prep[3u * i + 1], C = prep[3u * i + 2];
+            const float k = (float)((double)A.x * A.w + (double)A.y * B.w + (double)A.z * C.w);
+            const float E = ((__builtin_fabsf(B.x) + __builtin_fabsf(B.y) + __builtin_fabsf(B.z)) * up) * ((__builtin_fabsf(C.x) + __builtin_fabsf(C.y) + __builtin_fabsf(C.z)) * up) * up;
+            const float G = 0x1p-17f * E;
+            const float H = __builtin_fmaxf(G * ((__builtin_fabsf(A.x) + __builtin_fabsf(A.y) + __builtin_fabsf(A.z)) * up) * up, 0x1p-56f);
+            gmax = __builtin_fmaxf(gmax, G); hmax = __builtin_fmaxf(hmax, H);
+            const float n[3] = {A.w, B.w, C.w}, p0[3] = {A.x, A.y, A.z}, e1[3] = {B.x, B.y, B.z}, e2[3] = {C.x, C.y, C.z};
+            uint32_t cl = 3u;
+            for (uint32_t a = 0; a < 3u; ++a)
+                if (n[a] != 0.0f && n[(a + 1u) % 3u] == 0.0f && n[(a + 2u) % 3u] == 0.0f && e1[a] == 0.0f && e2[a] == 0.0f) cl = a;
+            cls[i - lo] = cl;
+            if (cl < 3u) { key[i - lo][0] = canon(p0[cl]); key[i - lo][1] = __float_as_uint(n[cl]); key[i - lo][2] = 0u; key[i - lo][3] = 0u; }
+            else { key[i - lo][0] = canon(n[0]); key[i - lo][1] = canon(n[1]); key[i - lo][2] = canon(n[2]); key[i - lo][3] = canon(k); }
         }
-        hdr[c] = lo < count ? np - hdr[4u + c] : 0u;
-        hdr[8u + c] = __float_as_uint(gmax); hdr[12u + c] = __float_as_uint(hmax);   // the chunk's largest margin constants (PT_SWEEP_UNIFORM_MARGIN)
-        if (np & 1u) { ent[2u * np] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ent[2u * np + 1u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ++np; }   // run = 0: shifts nothing in
+        hdr[8u + c] = __float_as_uint(gmax); hdr[12u + c] = __float_as_uint(hmax);
+        uint32_t packed = 0u;
+        for (uint32_t cl = 0; cl < 4u; ++cl) {
+            const uint32_t per = cl < 3u ? 4u : 2u, words = cl < 3u ? 4u : 8u;   // entries per group, words per entry
+            uint32_t n_ent = 0;
+            uint32_t* base = ent + 16u * groups;
+            uint32_t done = 0u;   // records of this class already in an entry
+            for (uint32_t i = 0; i < hi - lo; ++i) {
+                if (cls[i] != cl || (done >> i & 1u)) continue;
+                uint32_t mask = 0u, back = 0u;
+                // the same plane; the same plane reversed: every key word that is a float negated (zeros stay zeros; an axis plane keeps its coordinate)
+                for (uint32_t j = i; j < hi - lo; ++j) {
+                    if (cls[j] != cl || (done >> j & 1u)) continue;
+                    bool same = true, rev = true;
+                    for (uint32_t w = 0; w < 4u; ++w) {
+                        const uint32_t a = key[i][w], b = key[j][w];
+                        same = same && a == b;
+                        const bool coord = cl < 3u && w == 0u;   // q: not a signed quantity of the normal
+                        rev = rev && (coord || a == 0u ? a == b : (a ^ 0x80000000u) == b);
+                    }
+                    if (same) { mask |= 0x80000000u >> j; done |= 1u << j; }
+                    else if (rev) { back |= 0x80000000u >> j; done |= 1u << j; }
+                }
+                uint32_t* e = base + words * n_ent;
+                for (uint32_t w = 0; w < words; ++w) e[w] = 0u;
+                if (cl < 3u) { e[0] = key[i][0]; e[1] = key[i][1]; e[2] = mask; e[3] = back; }
+                else { e[0] = key[i][0]; e[1] = key[i][1]; e[2] = key[i][2]; e[3] = key[i][3]; e[4] = mask; e[5] = back; }
+                ++n_ent;
+            }
+            const uint32_t g = (n_ent + per - 1u) / per;
+            for (uint32_t w = words * n_ent; w < 16u * g; ++w) base[w] = 0u;   // padding entries: both masks zero
+            packed |= g << (8u * cl);
+            groups += g;
+        }
+        hdr[c] = packed;   // groups per class: x | y << 8 | z << 16 | general << 24
     }
 }
 
@@ -173,12 +198,10 @@ struct ParkT {
 };
 typedef ParkT<256, true> Park;
 
-PT_DEV Box set_box(const GridArgs& S) {
-    Box b;
-    b.lo = mk3(S.bound[0], S.bound[1], S.bound[2]);
-    b.hi = mk3(S.bound[4], S.bound[5], S.bound[6]);
-    return b;
-}
+PT_DEV Box set_box(const GridArgs& S) { return set_box_of(S); }
+#ifndef PT_SPHERE_LISTS
+#define PT_SPHERE_LISTS 1   // optimistic kernel: a staged single-cell sphere set through per-lane candidates (pt_trace.hpp trace_spheres1)
+#endif
 
 // closest hit over every set in upload order, z-buffered through ray.maxt
 // (A10 code.cl:675-800, 802-935, 937-1070; order A10 code.js:1809-1813)
@@ -192,7 +215,10 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const PARK& park
         Hit ch;
         ch.idx = UINT32_MAX;
         if (!GRIDS || S.n == 1u) {
-            if (live) {
+            if (PT_SPHERE_LISTS && PT_LANE_LISTS_FOR(FAST, GRIDS) && S.kind == KIND_SPHERES && S.lds_off != kNoLds) {   // wave-uniform (kernel arguments)
+                if (live) ch = trace_spheres1<false, false>(ray, rr, S);
+            } else if (live) {
+                pt_count(PC_BOX_TESTS); pt_count(PC_BOX_LANES, true);
                 const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(ray, rr, set_box(S));
                 if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, false, TRI_A10, FAST>(ray, bh, S) : trace_cell1<TRIANGLES, false, TRI_A10, FAST, false, PT_LANE_LISTS_FOR(FAST, GRIDS)>(ray, bh, S);
             }
@@ -274,7 +300,10 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             Hit ch;
             bool walked = false;
             if (!GRIDS || S.n == 1u) {
-                if (live) {
+                if (PT_SPHERE_LISTS && PT_LANE_LISTS_FOR(FAST, GRIDS) && S.kind == KIND_SPHERES && S.lds_off != kNoLds) {
+                    if (live) { ch = trace_spheres1<true, true>(sh, rr, S); walked = true; }
+                } else if (live) {
+                    pt_count(PC_BOX_TESTS); pt_count(PC_BOX_LANES, true);
                     const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(sh, rr, set_box(S));
                     if (bh.v) {
                         ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, true, TRI_A10, FAST, true>(sh, bh, S) : trace_cell1<TRIANGLES, true, TRI_A10, FAST, true, PT_LANE_LISTS_FOR(FAST, GRIDS)>(sh, bh, S);
@@ -298,6 +327,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             if (ch.idx != UINT32_MAX) sh.mint = ch.t;
         }
         if (!path || (uint32_t)poi.matId >= A.nmat) continue;  // out-of-range id: shade nothing (see k_sceneRender)
+        pt_count(PC_SHADE); pt_count(PC_SHADE_LANES, true);
         float4 c4 = material[poi.matId];
 #if PT_PARK_LDS
         if (PT_PARK_PN_FOR(GRIDS)) park.get_pn(poi);
@@ -322,10 +352,12 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 // 1024).  k > kLensTab: the lanes walk.
 constexpr uint32_t kLensTab = 64;
 __shared__ float pt_lens_tab[kLensTab];
+__shared__ uint32_t pt_blk_defer[4];   // in-pass resolve: "a sample of this block left the guard windows" (word 0; four words keep what follows 16-byte aligned)
 PT_DEV uint32_t lens_side(const FusedArgs& A) { return f2u_uniform(cl_sqrt((float)A.rpp)); }
 
 template <bool FAST, int GRIDS>
 PT_DEV void stage_block(const FusedArgs& A) {
+    if (threadIdx.x == 0u) pt_blk_defer[0] = 0u;
     if (A.rpp > 1u && threadIdx.x == 0u) {
         const uint32_t side = lens_side(A);
         if (side <= kLensTab) {
@@ -339,7 +371,11 @@ PT_DEV void stage_block(const FusedArgs& A) {
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
             if (S.lds_off == kNoLds) continue;
-            if (S.n == 1u) {
+            if (S.n == 1u && S.kind == KIND_SPHERES) {
+                if (!(PT_SPHERE_LISTS && PT_LANE_LISTS_FOR(FAST, GRIDS))) continue;
+                const uint32_t* src = (const uint32_t*)S.prims;   // float4 (c, r^2) per sphere
+                for (uint32_t k = threadIdx.x; k < S.nslots * 4u; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
+            } else if (S.n == 1u) {
                 if (!PT_LANE_LISTS_FOR(FAST, GRIDS)) continue;
                 // [records 12 words each][vertex normals 12 words each][material ids, one word each: a mesh's single id repeated]
                 const uint32_t words = S.nslots * 12u;
@@ -400,6 +436,39 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
     return ray;
 }
 
+// copyToPixel inside the pass (A10 code.cl:1366-1386) for the block that holds ray ids [first, first + 256): `rows` = the block's parked
+// accumulators, [channel][lane] (rows 0..3 of the park area), final for every lane (the caller's barrier).  rpp divides 256, so the block
+// holds 256 / rpp whole pixels; one lane per (pixel, channel) adds that pixel's rpp samples in the reference's order -- sequential in i,
+// from +0: the fp32 sum is order-dependent -- reading them four at a time (a channel's row is contiguous in LDS); the four lanes of a pixel
+// (one DPP quad) hand their sums to the first, which writes `radiance` (the sums) and `pixel` (the tone-scaled RGBA8, truncating).
+PT_DEV void resolve_block(const FusedArgs& A, const float* rows, uint64_t first, uint64_t n_local) {
+    const uint32_t rpp = A.rpp, ppb = 256u / rpp;
+    const uint32_t pix0 = (uint32_t)(first / rpp), npix = (uint32_t)(n_local / rpp);
+    for (uint32_t q = threadIdx.x; q < 4u * ppb; q += 256u) {   // whole quads: 4 ppb is a multiple of 4, and so is every q - threadIdx.x
+        const uint32_t j = q >> 2, c = q & 3u;
+        const float* r = rows + c * 256u + j * rpp;
+        float s = 0.0f;
+        if (rpp >= 4u) {
+            const float4* r4 = (const float4*)r;   // 16-byte aligned: the rows are, and rpp is a multiple of 4
+            for (uint32_t i = 0; i < rpp / 4u; ++i) { const float4 v = r4[i]; s += v.x; s += v.y; s += v.z; s += v.w; }
+        } else {
+            for (uint32_t i = 0; i < rpp; ++i) s += r[i];
+        }
+        const int si = (int)__float_as_uint(s);
+        const float x = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp(si, 0x00, 0xf, 0xf, true));   // quad_perm [0,0,0,0]
+        const float y = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp(si, 0x55, 0xf, 0xf, true));   // [1,1,1,1]
+        const float z = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp(si, 0xaa, 0xf, 0xf, true));   // [2,2,2,2]
+        const float w = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp(si, 0xff, 0xf, 0xf, true));   // [3,3,3,3]
+        if (c != 0u || pix0 + j >= npix) continue;
+        if (A.radiance) ((float4*)A.radiance)[pix0 + j] = make_float4(x, y, z, w);
+        if (A.pixel) {
+            const float sc = 255.0f * A.res_m;
+            const float cx = cl_clamp((x * sc) * 1.8f, 0.0f, 255.0f), cy = cl_clamp((y * sc) * 1.8f, 0.0f, 255.0f), cz = cl_clamp((z * sc) * 1.8f, 0.0f, 255.0f);
+            ((uchar4*)A.pixel)[pix0 + j] = make_uchar4((unsigned char)f2u(cx), (unsigned char)f2u(cy), (unsigned char)f2u(cz), 255);
+        }
+    }
+}
+
 #ifndef PT_FUSED_WAVES
 #define PT_FUSED_WAVES 6   // waves per SIMD the register allocator must leave room for (A/B without SLP packing: 5 -> 182.8 ms, 6 -> 178.3, 7 -> 181.0, 8 -> 192.1)
 #endif
@@ -441,25 +510,36 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
     // GRIDS: the walk shares its triangle tests across the wave (pt_trace_coop.hpp), so every lane stays in to the end: a lane
     // without a sample of its own (past the end of the tile; no bit left in its redo word) rides along on the tile's last sample
     // and writes nothing.
-    uint64_t base = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // In-pass resolve (A.resolve): the unit of everything is the BLOCK of 256 consecutive ray ids -- the optimistic kernel hands a whole block
+    // over when one of its samples left the guard windows (a bit per block in `defer_mask`; nothing of the block is written), and the exact
+    // kernel's redo mode is one block per 32-block word of that mask, every thread one sample of each marked block in turn.  Every thread stays
+    // in to the block's barrier: a lane past the end of the tile rides along as in the grid kernels.
+    uint64_t base = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // (every launch of this kernel uses 256-thread blocks: launch_fused)
     uint32_t todo = 1u;
+    uint32_t stride = 1u;
     if (!FAST && redo_mask) {
-        if (GRIDS) todo = base < redo_words ? redo_mask[base] : 0u;
-        else {
-            if (base >= redo_words) return;
-            todo = redo_mask[base];
+        if (A.resolve) {
+            todo = redo_mask[blockIdx.x];   // (the grid is one block per word)
+            base = (uint64_t)blockIdx.x * (32u * 256u) + threadIdx.x;
+            stride = 256u;
+        } else {
+            if (GRIDS) todo = base < redo_words ? redo_mask[base] : 0u;
+            else {
+                if (base >= redo_words) return;
+                todo = redo_mask[base];
+            }
+            base *= 32u;
         }
-        base *= 32u;
     }
   for (;; todo &= todo - 1u) {
     bool valid = todo != 0u;
     if (GRIDS) { if (__builtin_amdgcn_ballot_w64(valid) == 0ull) break; }
     else if (!valid) break;
     // the id is checked in 64 bits (the last block of a tile of nearly 2^32 rays reaches past it) and kept in 32
-    const uint64_t lid64 = base + (valid ? (uint32_t)__builtin_ctz(todo) : 0u);
+    const uint64_t lid64 = base + (valid ? (uint32_t)__builtin_ctz(todo) * stride : 0u);
     uint32_t lid = (uint32_t)lid64;
     if (lid64 >= n_local) {
-        if (!GRIDS) return;
+        if (!GRIDS && !A.resolve) return;
         valid = false;
         lid = (uint32_t)(n_local - 1u);
     }
@@ -469,7 +549,7 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
     if (!A.fresh) acc = ((const float4*)A.acu)[lid];
     Park park;
 #if PT_PARK_LDS
-    __shared__ float park_mem[PT_PARK_WORDS(GRIDS)][256];
+    __shared__ __attribute__((aligned(16))) float park_mem[PT_PARK_WORDS(GRIDS)][256];
     park.base = &park_mem[0][threadIdx.x];
     park.put(0, acc.x); park.put(1, acc.y); park.put(2, acc.z); park.put(3, acc.w);
     park.put(4, 1.0f); park.put(5, 1.0f); park.put(6, 1.0f);
@@ -482,9 +562,12 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
     poi.matId = -1;
 
     // segment 0 is the primary ray; segments 1..bounces start with bouncePaths (code.js:1829-1846)
+    pt_count(PC_WAVES);
     for (uint32_t seg = 0; seg <= A.bounces; ++seg) {
+        pt_count(PC_SEGMENTS);
         if (seg > 0) {
             if (poi.matId >= 0) {
+                pt_count(PC_BOUNCE); pt_count(PC_BOUNCE_LANES, true);
 #if PT_PARK_LDS
                 if (PT_PARK_PN_FOR(GRIDS)) park.get_pn(poi);
 #endif
@@ -494,6 +577,7 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
                 ray.maxt = PT_INF;
             }
         }
+        if (PT_COUNT && !(ray.mint == ray.maxt)) pt_count(PC_SEG_LANES, true);
         closest_all<FAST, GRIDS, Park>(A, ray, poi, park, defer);
         if (seg == 0) {
             for (uint32_t l = 0; l < A.n_lights; ++l) {  // lightRender (code.cl:600-629), primary segment only
@@ -521,7 +605,30 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
         asm volatile("" : "+v"(t));
         const uint64_t again = (uint64_t)blockIdx.x * 256u + t;
         lid = (uint32_t)again;
-        if (GRIDS) valid = again < n_local;   // (a lane past the end of the tile rode along on the tile's last sample)
+        if (GRIDS || A.resolve) valid = again < n_local;   // (a lane past the end of the tile rode along on the tile's last sample)
+    }
+    if (A.resolve) {   // wave-uniform (a kernel argument)
+#if !PT_PARK_LDS
+        __shared__ __attribute__((aligned(16))) float park_mem[4][256];
+        park_mem[0][threadIdx.x] = acc.x; park_mem[1][threadIdx.x] = acc.y; park_mem[2][threadIdx.x] = acc.z; park_mem[3][threadIdx.x] = acc.w;
+#endif
+        if (FAST && defer) pt_blk_defer[0] = 1u;
+        __syncthreads();   // every lane's accumulator is final in LDS, and so is the flag
+        if (FAST && pt_blk_defer[0] != 0u) {   // the whole block goes to the exact kernel: its seeds stay as they were, no pixel of it is written
+            if (threadIdx.x == 0u) atomicOr(&defer_mask[blockIdx.x >> 5], 1u << (blockIdx.x & 31u));
+            return;
+        }
+        if (valid) {
+            A.seeds[lid] = seed;
+            if (A.acu) ((float4*)A.acu)[lid] = make_float4(park_mem[0][threadIdx.x], park_mem[1][threadIdx.x], park_mem[2][threadIdx.x], park_mem[3][threadIdx.x]);
+        }
+        // the block's first ray id: wave-uniform (blockIdx alone in the optimistic kernel; the marked block of this trip in the redo loop)
+        const uint64_t first = FAST ? (uint64_t)blockIdx.x * 256u
+                                    : (uint64_t)blockIdx.x * (stride == 256u ? 32u * 256u : 256u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctz(todo)) * stride;
+        resolve_block(A, &park_mem[0][0], first, n_local);
+        if (FAST) return;
+        __syncthreads();   // the redo loop's next block parks into the same rows
+        continue;
     }
     // The optimistic kernel has one sample per thread: it LEAVES here, so the compiler sees a straight-line body and not a loop (the
     // exact kernel's redo mode does loop over the set bits of its word).  As a loop -- its exit in the grid kernels is a wave ballot, opaque
@@ -570,14 +677,24 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
     const uint32_t tri_base = grids ? kCoopWordsPerBlock + (staged ? (uint32_t)used : 0u) : 0u;   // multiples of 4 words: kCoopWordsPerBlock is, `used` is rounded up below
     const uint32_t tri_base4 = (tri_base + 3u) & ~3u;
     if (fast && PT_LANE_LISTS_FOR(true, grids ? 1 : 0)) {
+        uint32_t tris = 0;
         for (uint32_t i = 0; i < b.n_sets; ++i) {
             GridArgs& S = b.sets[i];
-            if (S.n != 1u || S.kind != KIND_TRIANGLES || !S.pnorm || S.nslots == 0u || tri_words / 28u + S.nslots > kLdsTriMax) continue;
+            if (S.n != 1u || S.kind != KIND_TRIANGLES || !S.pnorm || S.nslots == 0u || tris + S.nslots > kLdsTriMax) continue;
             S.lds_off = tri_base4 + tri_words;
             tri_words += S.nslots * 28u;   // records, vertex normals, material ids (stage_block), rounded up to whole float4s
+            tris += S.nslots;
+        }
+        // ... and the single-cell sphere sets (four words a sphere) for trace_spheres1; `first_zero`: the set's one cell starts at slot 0 (the host checked)
+        for (uint32_t i = 0; PT_SPHERE_LISTS && i < b.n_sets; ++i) {
+            GridArgs& S = b.sets[i];
+            if (S.n != 1u || S.kind != KIND_SPHERES || S.nslots == 0u || S.nslots > kLdsSphMax || !S.first_zero) continue;
+            S.lds_off = tri_base4 + tri_words;
+            tri_words += S.nslots * 4u;
         }
     }
-    const dim3 grid((unsigned)((n + 255) / 256));
+    // redo mode: one thread per 32-sample word of the mask, or (in-pass resolve: the mask is per block) one block per 32-block word
+    const dim3 grid(redo_mask && a.resolve ? (unsigned)redo_words : (unsigned)((n + 255) / 256));
     // dynamic LDS: the waves' exchange areas, then the staged tables (what the scene needs, not the 16 KB cap: occupancy), then the staged triangles
     const size_t lds_tri = tri_words ? (size_t)(tri_base4 - tri_base + tri_words) * 4u : 0u;
     const size_t lds2 = (size_t)kCoopWordsPerBlock * 4u + lds_tri, lds = (size_t)kCoopWordsPerBlock * 4u + (staged ? (size_t)used * 4u : 0u) + lds_tri;
@@ -599,15 +716,22 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
     }
 }
 bool fused_fast_available() { return PT_EXACT_FAST_DIV != 0; }
+#if PT_COUNT
+int debug_counters(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_counters), sizeof(unsigned long long) * PC_COUNT) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[PC_COUNT] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pt_counters), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 void launch_deferCount(hipStream_t s, const uint32_t* mask, uint32_t words, uint32_t* count) {
     if (words) hipLaunchKernelGGL(k_deferCount, dim3((words + 255) / 256), dim3(256), 0, s, mask, words, count);
 }
 
-size_t prepared_bytes(uint32_t count) { return prepared_planes_offset(count) + (count <= kLdsTriMax ? 64 + ((size_t)count + 8) * 32 : 0); }
+size_t prepared_bytes(uint32_t count) { return prepared_planes_offset(count) + (count <= kLdsTriMax ? prepared_planes_bytes(count) : 0); }
 void launch_prepTriangles(hipStream_t s, const void* pos, void* out, uint32_t count, uint32_t* insane_word) {
     if (!count) return;
     hipLaunchKernelGGL(k_prepTriangles, dim3((count + 255) / 256), dim3(256), 0, s, (const float4*)pos, (float4*)out, count, insane_word);
-    if (count <= kLdsTriMax) hipLaunchKernelGGL(k_planeRuns, dim3(1), dim3(64), 0, s, (const float4*)out, count, (float4*)((char*)out + prepared_planes_offset(count)));
+    if (count <= kLdsTriMax) hipLaunchKernelGGL(k_planeList, dim3(1), dim3(64), 0, s, (const float4*)out, count, (uint32_t*)((char*)out + prepared_planes_offset(count)));
 }
 
 }  // namespace pt

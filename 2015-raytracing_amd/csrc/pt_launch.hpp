@@ -39,11 +39,14 @@ constexpr uint32_t kLdsTriMax = 96;       // single-cell triangle sets staged in
                                           // 112 B per triangle): 10.5 KB per block at most
 struct GridArgs {            // one cell-sorted primitive set, device pointers
     const void* prims;       // float4 per sphere (c, r^2) | 3 x float4 per PREPARED triangle (launch_prepTriangles)
-    const void* pnorm;       // triangles, at most kLdsTriMax records: the candidate sweep's PLANE list behind the records and group spheres
-                             // (prepared_planes_offset; k_planeRuns writes it): a 64-byte header {planes[4], first[4], Gmax[4], Hmax[4]} per chunk of 32 records, then
-                             // 32 bytes per plane {n.xyz, k = p0 . n, G, H, run, 0}: n = cross(e2, e1), the two constants of the plane-window margin
-                             // M = G |o|_1 + H, and how many CONSECUTIVE records (1 or 2: the halves of a quad) lie in it bit for bit.  Read by scalar
-                             // loads in the sweep (pt_trace.hpp trace_cell1).  Null: no list (the set runs the wave-uniform loop)
+    const void* pnorm;       // triangles, at most kLdsTriMax records: the candidate sweep's PLANE LIST behind the records and group spheres
+                             // (prepared_planes_offset; k_planeList writes it).  A 64-byte header, one slot per chunk of 32 records:
+                             // {groups[4], first[4], Gmax[4], Hmax[4]} -- groups = 64-byte groups per class (x | y << 8 | z << 16 | general << 24),
+                             // first = the chunk's first group, Gmax / Hmax = the chunk's largest margin constants (M = G |o|_1 + H).  Then the
+                             // groups: axis planes {q, n_a, mask, back mask} four to a group, general planes {n.xyz, k = p0 . n, mask, back
+                             // mask, 0, 0} two to a group; mask = the chunk's records in that plane (record c0 + j at bit 31 - j), back mask = those
+                             // in the same plane with the normal reversed.  Read by scalar loads in the sweep (pt_trace.hpp trace_cell1).
+                             // Null: no list (the set runs the wave-uniform loop)
     const void* normals;     // 3 x float4 per triangle (null for spheres)
     const void* matid;       // uint per primitive (null: use `mesh_matid`)
     const void* off;         // uint[n^3 + 1]
@@ -58,6 +61,7 @@ struct GridArgs {            // one cell-sorted primitive set, device pointers
                              // 4) of the set's `nslots` prepared records staged in LDS for the per-lane candidate loops, or kNoLds
     float delta[3], rdelta[3]; // n > 1, optimistic kernel: the cell width per axis (hi - lo) / n and its reciprocal, both correctly rounded --
     uint32_t nslots;         // off[n^3], the number of (cell, primitive) slots, when the host knows it (0: the walk reads it from the table)
+    uint32_t first_zero;     // off[0] == 0 (host-checked): a single-cell set's list is slots [0, nslots)
     uint32_t walk_ok;        // what every lane would compute for itself from wave-uniform inputs (pt_trace.hpp axis_setup_t).  walk_ok: the
                              // widths and spans sit inside the windows in which the kernel's 3-operation divisions are exact; a lane that
                              // walks a set without it hands its sample to the exact kernel
@@ -85,7 +89,17 @@ struct FusedArgs {
     void* acu;               // float4[nrows*width*rpp], accumulated into
     const void* uv;          // rpp == 1: float2[nrows*width] lens draws from launch_lensDraws
     uint32_t fresh;          // 1: the accumulator starts at zero and is not read (initAcu folded into the pass, mirt_render_first_pass)
+    // copyToPixel INSIDE the pass (A10 code.cl:1366-1386; `resolve` != 0): a block of 256 consecutive ray ids holds whole pixels (rpp divides 256) and the
+    // pass is a frame's first, so every accumulator of a pixel is final in the block's LDS when its last sample ends: the block sums them in the
+    // reference's order and writes `pixel` (RGBA8) and / or `radiance` (the un-scaled sums); `acu` may then be null -- nothing per ray but the seed
+    // touches memory: 8 B per sample + 20 B per pixel.  launch_fused decides (fused_resolves()).
+    void* pixel;             // uchar4[nrows*width] or null
+    void* radiance;          // float4[nrows*width] or null
+    float res_m;             // 1 / (rpp * passes), A10 code.js:1412
+    uint32_t resolve;
 };
+// whether a pass with these arguments resolves inside the kernel: first pass of a frame, whole pixels per block, somewhere to put the result
+inline bool fused_resolves(uint32_t rpp, bool fresh, bool want_out) { return fresh && want_out && rpp <= 256u && 256u % rpp == 0u; }
 // fast: the optimistic kernel (writes deferred samples' bits into defer_mask); !fast: the exact kernel over `list` (or everything)
 void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words);
 bool fused_fast_available();   // compiled with PT_EXACT_FAST_DIV
@@ -99,8 +113,9 @@ size_t prepared_bytes(uint32_t count);   // what `out` must hold for `count` tri
 #define PT_TRI_GROUP 16
 #endif
 constexpr uint32_t kTriGroup = PT_TRI_GROUP;   // prepared records per bounding sphere (pt_trace.hpp group_missed)
-// byte offset of the candidate sweep's plane list inside it (64-byte aligned): header, then at most count + 8 entries of 32 bytes (every chunk's
-// run of entries starts at an even index and is padded to an even length: two entries per s_load_dwordx16)
+// byte offset of the candidate sweep's plane list inside it (64-byte aligned), and its size: the header, then per chunk of 32 records at
+// most 32 general entries of 32 bytes (or 32 axis entries of 16) plus one partly filled 64-byte group per class
+inline size_t prepared_planes_bytes(uint32_t count) { return 64 + ((size_t)count + 31) / 32 * (32 * 32 + 4 * 64); }
 __host__ __device__ inline size_t prepared_planes_offset(uint32_t count) { return ((size_t)count * 48 + ((size_t)count + kTriGroup - 1) / kTriGroup * 16 + 63) & ~(size_t)63; }
 
 // ---- uniform-grid build on the device (pt_grid_build.hip) -------------------------------------------

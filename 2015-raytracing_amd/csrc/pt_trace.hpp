@@ -14,6 +14,27 @@
 
 namespace pt {
 
+// -DPT_COUNT=1: a profiling build (profiles/trip_counts.py) -- wave-level trip counters of the fused pass's loops, so the static instruction
+// count of each loop body can be weighted by how often it really runs.  One atomic per counted event from the first active lane; `lanes`
+// variants add the number of active lanes.  Not a product build: the counters are read through mirt_debug_counters, which only this build exports.
+#ifndef PT_COUNT
+#define PT_COUNT 0
+#endif
+enum PtCounter { PC_WAVES = 0, PC_SEGMENTS, PC_SEG_LANES, PC_Q_CLOSEST, PC_Q_CLOSEST_LANES, PC_SWEEP_CLOSEST, PC_TRIPS_CLOSEST, PC_TRIP_LANES_CLOSEST,
+                 PC_Q_SHADOW, PC_Q_SHADOW_LANES, PC_SWEEP_SHADOW, PC_TRIPS_SHADOW, PC_TRIP_LANES_SHADOW,
+                 PC_SPH_Q_CLOSEST, PC_SPH_Q_CLOSEST_LANES, PC_SPH_TESTS_CLOSEST, PC_SPH_ROOTS_CLOSEST, PC_SPH_Q_SHADOW, PC_SPH_Q_SHADOW_LANES, PC_SPH_TESTS_SHADOW, PC_SPH_ROOTS_SHADOW,
+                 PC_BOX_TESTS, PC_BOX_LANES, PC_SHADE, PC_SHADE_LANES, PC_BOUNCE, PC_BOUNCE_LANES, PC_COUNT = 32 };
+#if PT_COUNT
+static __device__ unsigned long long pt_counters[PC_COUNT];
+__device__ __forceinline__ void pt_count(int i, bool lanes = false) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+    const unsigned me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (me == (unsigned)__builtin_ctzll(m)) atomicAdd(&pt_counters[i], lanes ? (unsigned long long)__builtin_popcountll(m) : 1ull);
+}
+#else
+__device__ __forceinline__ void pt_count(int, bool = false) {}
+#endif
+
 struct Hit { uint32_t idx; float t, beta, gamma; };
 
 // Geometry the kernels only read, fetched in wave-uniform loops: through the CONSTANT address space, so the loads stay scalar
@@ -49,13 +70,6 @@ enum TriRule { TRI_A10 = 0, TRI_A07 = 1, TRI_A04 = 2 };
 #endif
 #ifndef PT_SPHERE_WAVE_SKIP
 #define PT_SPHERE_WAVE_SKIP 1
-#endif
-#ifndef PT_SWEEP_UNIFORM_MARGIN
-#define PT_SWEEP_UNIFORM_MARGIN 1   // the sweep's plane-window margin once per chunk of 32 records, from the chunk's largest constants (the header carries them),
-                                    // instead of one fma per plane from each plane's own: headline kernel 106.8 -> 104.8 ms
-#endif
-#ifndef PT_LANE_FILTER
-#define PT_LANE_FILTER 1   // the candidate sweep of trace_cell1 also drops triangles whose plane the ray meets outside its window
 #endif
 // WAVE_CULL (the wave-uniform loops: all lanes hold the SAME triangle): when the triangle faces away from every lane's ray
 // (div <= 0 in all of them: coherent primary and shadow rays against half of a closed room's walls) the rest of the test is skipped for the
@@ -283,13 +297,14 @@ PT_DEV SphereRay sphere_ray(f3 d) {
 // WAVE_SKIP (the wave-uniform loops: every lane holds the SAME sphere): when the discriminant is negative in every lane the square root and
 // the window tests are skipped for the wave -- the reference's early return (code.cl:206-209) taken when the whole wave takes it; a small
 // sphere is missed by all 64 rays of an incoherent wave about one time in five.
-template <bool ORDERED = false, bool WAVE_SKIP = false>
+template <bool ORDERED = false, bool WAVE_SKIP = false, int COUNTER = -1>
 PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, const float4 sph, float& t_out) {
     f3 omc = sub3(o, ld3(sph));
     float b = 2.0f * dot3(omc, d);
     float c = dot3(omc, omc) - sph.w;
     float dis = cl_mad(-4.0f * c, sr.a, b * b);
     if (WAVE_SKIP && __builtin_amdgcn_ballot_w64(!(dis < 0.0f)) == 0ull) { t_out = 0.0f; return false; }
+    if (COUNTER >= 0) pt_count(COUNTER);
     float sq = cl_sqrt(dis);
     float t0 = (-b - sq) * sr.inv2a;
     float t1 = (-b + sq) * sr.inv2a;
@@ -329,10 +344,43 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     return a;
 }
 
+// all ones where the sign bit of w is set, else zero.  As the instruction itself: from the C shift the compiler makes a compare, a move of the
+// mask into a VGPR, a select and an or (four instructions and an s_nop where the sweep needs two: this and one v_bitop3_b32)
+PT_DEV uint32_t sign_word(float w) {
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(w));
+    return r;
+}
+
 // The block's dynamic LDS (launch_fused sizes it): [cooperative-walk exchange area (pt_trace_coop.hpp)] [staged cell-offset tables]
 // [staged single-cell triangle sets]: GridArgs::lds_off indexes it.  The walks read it through THIS symbol, so the compiler knows the
 // address space and emits ds_read (through a generic pointer selected at run time it emitted flat_load pairs).
 extern __shared__ uint32_t pt_lds_dyn[];
+
+PT_DEV Box set_box_of(const GridArgs& S) {
+    Box b;
+    b.lo = mk3(S.bound[0], S.bound[1], S.bound[2]);
+    b.hi = mk3(S.bound[4], S.bound[5], S.bound[6]);
+    return b;
+}
+// The t at which a ray leaves the single cell of an n == 1 set: axis_setup with n == 1 -- slab = 0, the cell exit is the far face as the
+// reference computes it, lo + (0 + (d>=0)) * ((hi-lo)/1)   (A10 code.cl:699-707)
+PT_DEV float cell1_exit(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
+    float tn[3];
+    if (S.exit_is_far_face) {  // host-verified: the cell's exit planes ARE the box's far planes (see mirt_abi.cpp)
+        tn[0] = bh.tfx; tn[1] = bh.tfy; tn[2] = bh.tfz;
+    } else {
+        const float lo[3] = {S.bound[0], S.bound[1], S.bound[2]}, hi[3] = {S.bound[4], S.bound[5], S.bound[6]};
+        const float oo[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float delta = (hi[k] - lo[k]) / 1.0f;
+            float xnext = lo[k] + (float)((dd[k] >= 0) ? 1 : 0) * delta;
+            tn[k] = (xnext - oo[k]) / dd[k];
+        }
+    }
+    return cl_min(cl_min(tn[0], tn[1]), tn[2]);   // one v_min3_f32
+}
 
 // One primitive set.  KIND / ANY as in pt_device.hpp.
 // trace_cell1: n == 1, a single cell, every lane walks the same list -> wave-uniform loop, scalar loads.
@@ -356,89 +404,88 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
     ch.gamma = 0.0f;
     SphereRay sr;
     if (KIND == SPHERES) sr = sphere_ray<FAST>(ray.d);
-    // axis_setup with n == 1: slab = 0, the cell exit is the far face as the reference computes
-    // it, lo + (0 + (d>=0)) * ((hi-lo)/1)   (A10 code.cl:699-707)
-    float tn[3];
-    if (S.exit_is_far_face) {  // host-verified: the cell's exit planes ARE the box's far planes (see mirt_abi.cpp)
-        tn[0] = bh.tfx; tn[1] = bh.tfy; tn[2] = bh.tfz;
-    } else {
-        const float lo[3] = {S.bound[0], S.bound[1], S.bound[2]}, hi[3] = {S.bound[4], S.bound[5], S.bound[6]};
-        const float oo[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float delta = (hi[k] - lo[k]) / 1.0f;
-            float xnext = lo[k] + (float)((dd[k] >= 0) ? 1 : 0) * delta;
-            tn[k] = (xnext - oo[k]) / dd[k];
-        }
-    }
     const float cmin = bh.tmin;
-    const float cmax = cl_min(cl_min(tn[0], tn[1]), tn[2]);   // one v_min3_f32
+    const float cmax = cell1_exit(ray, bh, S);
     const uint32_t begin = __builtin_amdgcn_readfirstlane(ldc_u32(S.off, 0));
     const uint32_t end = __builtin_amdgcn_readfirstlane(ldc_u32(S.off, 1));
     bool done = false;
     if (LANES && KIND == TRIANGLES && FAST && RULE == TRI_A10 && S.lds_off != kNoLds && begin == 0u) {
-        // the sweep's plane list (k_planeRuns): a 64-byte header {planes[4], first[4], Gmax[4], Hmax[4]} (one slot per chunk of 32 records), then one entry per run of
-        // consecutive records in one plane: {n.xyz, k = p0.n} {G, H, run, 0}; two entries per s_load_dwordx16
+        // the sweep's plane list (k_planeList; layout in pt_launch.hpp): a 64-byte header {groups[4], first[4], Gmax[4], Hmax[4]} (one slot per chunk of 32
+        // records), then 64-byte groups of entries -- one s_load_dwordx16 each: four axis planes {q, n_a, mask, back mask} or two general ones
+        // {n.xyz, k = p0 . n, mask, back mask, 0, 0}; mask = the chunk's records in that plane, record c0 + j at bit 31 - j
         const pt_v16f PT_CONST_AS* pn = (const pt_v16f PT_CONST_AS*)((const char PT_CONST_AS*)S.pnorm + 64);
         const uint32_t lds_bytes = S.lds_off * 4u;
-#if PT_LANE_FILTER
-        // PLANE WINDOW (the second filter of the sweep).  A hit needs cmin <= t <= cmax and t < maxt (code.cl:273-280 and the callers'
-        // comparisons), where the reference's t = fl(dot(cross(s, e2), e1) * -(1 / div)).  In exact arithmetic that numerator is
-        // s . (e2 x e1) = o . n - p0 . n, which the sweep gets in three fused operations: sn = fma(n.z, o.z, fma(n.y, o.y, fma(n.x, o.x, -k))).
-        // Both evaluations stay within 14 u E (|o|_1 + |p0|_1) of each other (u = 2^-24, E = |e1|_1 |e2|_1: the rounding of s, of the two
-        // cross products, of the dot products, of n and of k, term by term); the sweep allows M = 2^-17 E (|o|_1 + |p0|_1), nine times
-        // that, never less than 2^-56, and widens the window by 2^-20 relative, which also covers the three roundings between the
-        // reference's numerator and its t and those of the two tests below (PT_SWEEP_UNIFORM_MARGIN: every plane of a chunk gets the chunk's LARGEST
-        // G and H -- a wider margin keeps more, never less).  With div > 0:
+        // PLANE WINDOW (the second filter of the sweep; the first is the facing test div > 0).  A hit needs cmin <= t <= cmax and t < maxt
+        // (code.cl:273-280 and the callers' comparisons), where the reference's t = fl(dot(cross(s, e2), e1) * -(1 / div)).  In exact arithmetic
+        // that numerator is s . (e2 x e1) = o . n - p0 . n, which the sweep gets in three fused operations: sn = fma(n.z, o.z, fma(n.y, o.y,
+        // fma(n.x, o.x, -k))) -- or, for a plane {x_a = q} (an AXIS entry: n = n_a e_a exactly, every vertex at x_a = q), sn = n_a (o_a - q) and
+        // div = n_a d_a, which is what the reference's three-term dot product comes to when two terms are products with zero (the sign of a
+        // zero result aside, and a zero div is a reject either way).  Both evaluations of the numerator stay within 14 u E (|o|_1 + |p0|_1) of
+        // each other (u = 2^-24, E = |e1|_1 |e2|_1: the rounding of s, of the two cross products, of the dot products, of n and of k, term by
+        // term; the axis form has two roundings, each relative to |n_a| (|o_a| + |q|) <= E (|o|_1 + |p0|_1)); the sweep allows
+        // M = 2^-17 E (|o|_1 + |p0|_1), nine times that, never less than 2^-56, and widens the window by 2^-20 relative, which also covers the
+        // three roundings between the reference's numerator and its t and those of the two tests below (every plane of a chunk gets the
+        // chunk's LARGEST G and H -- a wider margin keeps more, never less).  With div > 0:
         //   -sn - M > hi+ * div,  hi+ = max(min(cmax, maxt) * (1 + 2^-20), 2^-100)   =>   the reference's t > min(cmax, maxt): no hit
         //   -sn + M < lo- * div,  lo- = cmin * (1 - 2^-20)                            =>   the reference's t < cmin, and at least
         //        2^-57 / 2^82 in magnitude when cmin = 0 (no underflow to a -0 that would pass t >= 0): no hit
         // so such a triangle is not a candidate: every test the lane skips is one the reference's own window rejects, and the tests it
-        // does run are the reference's.  min3 drops a NaN operand (then the triangle stays a candidate); lanes outside the guard
-        // windows are deferred to the exact kernel whatever they compute here.  In cornell.xml a closest query keeps 2-4 of the 5-7
-        // front-facing triangles (the wall the ray leaves through, sometimes the free-standing triangle's plane), a shadow query 0-2.
+        // does run are the reference's.  w = min3(div, c, -a) carries the verdict in its sign (min3 drops a NaN operand: then the triangle
+        // stays a candidate; lanes outside the guard windows are deferred to the exact kernel whatever they compute here).  The BACK mask of
+        // an entry holds the records with the reversed normal: -n, -k negate div and sn exactly, so their verdict is
+        // min3(-div, -fma(hi+, div, sn - M), fma(lo-, div, sn + M)) -- two more fused operations on sums the front verdict already made.
+        // In cornell.xml a closest query keeps 2-4 of the 5-7 front-facing triangles, a shadow query 0-2.
         const float o1 = __builtin_fabsf(ray.o.x) + __builtin_fabsf(ray.o.y) + __builtin_fabsf(ray.o.z);
         const float hi_p = __builtin_fmaxf(__builtin_fminf(cmax, ray.maxt) * 1.00000095367431640625f, 0x1p-100f);
         const float lo_m = cmin * 0.99999904632568359375f;
-#endif
+        pt_count(ANY ? PC_Q_SHADOW : PC_Q_CLOSEST); pt_count(ANY ? PC_Q_SHADOW_LANES : PC_Q_CLOSEST_LANES, true);
         for (uint32_t c0 = 0u; c0 < end; c0 += 32u) {
-            const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u;
-            const uint32_t planes = ldc_u32(S.pnorm, c0 >> 5), first = ldc_u32(S.pnorm, 4u + (c0 >> 5));
-#if PT_LANE_FILTER && PT_SWEEP_UNIFORM_MARGIN
+            const uint32_t groups = ldc_u32(S.pnorm, c0 >> 5);
+            const pt_v16f PT_CONST_AS* g = pn + ldc_u32(S.pnorm, 4u + (c0 >> 5));
             const float Mu = cl_fma(__uint_as_float(ldc_u32(S.pnorm, 8u + (c0 >> 5))), o1, __uint_as_float(ldc_u32(S.pnorm, 12u + (c0 >> 5))));
-#endif
-            uint32_t neg = 0u;
-            for (uint32_t g = 0; g < (planes + 1u) >> 1; ++g) {
-                const pt_v16f v = pn[(first >> 1) + g];
+            uint32_t cand = 0u;
+            // the verdict of one plane from its div and sn: candidates |= mask where w >= 0 (sign bit clear)
+            auto verdict = [&](float div, float sn, uint32_t mask, uint32_t back) {
+                const float sp = sn + Mu, sm = sn - Mu;
+                const float w = __builtin_fminf(__builtin_fminf(div, cl_fma(hi_p, div, sp)), -cl_fma(lo_m, div, sm));   // one v_min3_f32
+                cand |= mask & ~sign_word(w);
+                if (back != 0u) {   // wave-uniform (an SGPR)
+                    asm volatile("" ::: "memory");
+                    const float wb = __builtin_fminf(__builtin_fminf(-div, -cl_fma(hi_p, div, sm)), cl_fma(lo_m, div, sp));
+                    cand |= back & ~sign_word(wb);
+                }
+            };
+#define PT_AXIS_GROUPS(SHIFT, OA, DA)                                                                                   \
+            for (uint32_t i = 0; i < ((groups >> SHIFT) & 255u); ++i, ++g) {                                            \
+                const pt_v16f v = *g;                                                                                   \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                         \
+                    const uint32_t mask = __float_as_uint(v[4 * k + 2]), back = __float_as_uint(v[4 * k + 3]);          \
+                    if ((mask | back) == 0u) continue;   /* a padding entry: skipped on a scalar branch */              \
+                    asm volatile("" ::: "memory");                                                                      \
+                    pt_count(ANY ? PC_SWEEP_SHADOW : PC_SWEEP_CLOSEST);                                                 \
+                    verdict(v[4 * k + 1] * (DA), v[4 * k + 1] * ((OA) - v[4 * k]), mask, back);                         \
+                }                                                                                                       \
+            }
+            PT_AXIS_GROUPS(0, ray.o.x, ray.d.x)
+            PT_AXIS_GROUPS(8, ray.o.y, ray.d.y)
+            PT_AXIS_GROUPS(16, ray.o.z, ray.d.z)
+#undef PT_AXIS_GROUPS
+            for (uint32_t i = 0; i < groups >> 24; ++i, ++g) {
+                const pt_v16f v = *g;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const uint32_t run = __float_as_uint(v[8 * k + 6]);   // wave-uniform (an SGPR): 1 or 2 records in this plane, 0 for the padding entry
-                    if (run == 0u) continue;
+                    const uint32_t mask = __float_as_uint(v[8 * k + 4]), back = __float_as_uint(v[8 * k + 5]);
+                    if ((mask | back) == 0u) continue;
                     asm volatile("" ::: "memory");   // keeps the skip a scalar branch (the compiler would rather compute the padding entry and select)
+                    pt_count(ANY ? PC_SWEEP_SHADOW : PC_SWEEP_CLOSEST);
                     const float div = dot3(mk3(v[8 * k], v[8 * k + 1], v[8 * k + 2]), ray.d);
-#if PT_LANE_FILTER
                     const float sn = cl_fma(v[8 * k + 2], ray.o.z, cl_fma(v[8 * k + 1], ray.o.y, cl_fma(v[8 * k], ray.o.x, -v[8 * k + 3])));
-#if PT_SWEEP_UNIFORM_MARGIN
-                    const float M = Mu;   // the largest margin of the chunk for every plane of it: wider is always safe
-#else
-                    const float M = cl_fma(v[8 * k + 4], o1, v[8 * k + 5]);
-#endif
-                    const float c = cl_fma(hi_p, div, sn + M), a = cl_fma(lo_m, div, sn - M);
-                    const float w = __builtin_fminf(__builtin_fminf(div, c), -a);   // one v_min3_f32; negative: not a candidate
-#else
-                    const float w = div;
-#endif
-                    // (neg << 1) | sign, once per record of the run (the second one behind a scalar branch)
-                    neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(w), 31);
-                    if (run >= 2u) {
-                        asm volatile("" ::: "memory");
-                        neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(w), 31);
-                    }
+                    verdict(div, sn, mask, back);
                 }
             }
-            uint32_t cand = ~neg << (32u - cnt);   // record c0 + k at bit 31 - k
             if (ANY && done) cand = 0u;            // (a set of more than 32 triangles: a blocked lane sits the later sweeps out)
             while (cand != 0u) {
+                pt_count(ANY ? PC_TRIPS_SHADOW : PC_TRIPS_CLOSEST); pt_count(ANY ? PC_TRIP_LANES_SHADOW : PC_TRIP_LANES_CLOSEST, true);
                 const uint32_t k = (uint32_t)__builtin_clz(cand);
                 cand &= ~(0x80000000u >> k);
                 const uint32_t i = c0 + k;
@@ -461,6 +508,7 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         if (ANY && FLAG_ONLY && done) ch.idx = 0u;
         return ch;
     }
+    if (KIND == SPHERES) { pt_count(ANY ? PC_SPH_Q_SHADOW : PC_SPH_Q_CLOSEST); pt_count(ANY ? PC_SPH_Q_SHADOW_LANES : PC_SPH_Q_CLOSEST_LANES, true); }
     const pt_v4f PT_CONST_AS* p = (const pt_v4f PT_CONST_AS*)S.prims + (size_t)begin * (KIND == SPHERES ? 1u : 3u);   // one running pointer: immediate-offset scalar loads
 #if PT_UNROLL_UNIFORM > 1
 #pragma unroll PT_UNROLL_UNIFORM
@@ -469,7 +517,8 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
         float ti, b = 0.0f, gm = 0.0f;
         bool hit;
         if (KIND == SPHERES) {
-            hit = sph_test<FAST, PT_SPHERE_WAVE_SKIP != 0>(ray.o, ray.d, sr, cmin, cmax, ldc4((const void*)p, 0), ti);
+            pt_count(ANY ? PC_SPH_TESTS_SHADOW : PC_SPH_TESTS_CLOSEST);
+            hit = sph_test<FAST, PT_SPHERE_WAVE_SKIP != 0, ANY ? PC_SPH_ROOTS_SHADOW : PC_SPH_ROOTS_CLOSEST>(ray.o, ray.d, sr, cmin, cmax, ldc4((const void*)p, 0), ti);
         } else {
             hit = tri_test<RULE, FAST, PT_UNIFORM_CULL != 0>(ray.o, ray.d, cmin, cmax, ldc4((const void*)p, 0), ldc4((const void*)p, 1), ldc4((const void*)p, 2), ti, b, gm);
         }
@@ -487,6 +536,83 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
             done = done || better;
             if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every lane of the wave is blocked
         }
+    }
+    if (ANY && FLAG_ONLY && done) ch.idx = 0u;
+    return ch;
+}
+
+// A single-cell SPHERE set of the optimistic kernel through per-lane candidates (the spheres staged in the block's LDS: S.lds_off).
+// The wave-uniform loop of trace_cell1 runs the set's box test and then every sphere's whole test -- discriminant, square root, both roots,
+// the window -- for the wave, whatever share of its lanes can hit (cornell.xml: two spheres, a third of the lanes inside their box, and the
+// set was a quarter of the kernel).  Here the order is the reference's own early return first (code.cl:206-209, dis < 0), for every sphere
+// of the set in one wave-uniform sweep: omc, b, c and dis = mad(-4c, a, b b) with the reference's operations (14 instructions), the sign
+// of dis shifted into a per-lane word.  dis is -0 for no input (b b is +0 or positive, and (-0) + (+0) = +0), so "sign bit clear" is
+// exactly !(dis < 0) except for a NaN, whose test the reference's own comparisons reject wherever its sign bit says.  Only when some lane
+// of the wave holds a candidate does the set's BOX run at all -- interAABB (code.cl:335-389) gives nothing but the verdict and the window
+// [cmin, cmax] the roots are compared with, and a lane without a candidate has no root -- and then every lane walks ITS OWN candidates in
+// list order: the record from LDS, the same discriminant again (same operations, same bits), the root stage.  Ties on t go to the lower
+// index as in the reference's loop (strict <); a shadow lane stops at its first blocker.
+constexpr uint32_t kLdsSphMax = 64;   // spheres per staged set (4 words each)
+template <bool ANY, bool FLAG_ONLY>
+PT_DEV Hit trace_spheres1(const Ray& ray, const RayRcp& rr, const GridArgs& S) {
+    Hit ch;
+    ch.idx = UINT32_MAX;
+    ch.t = ray.maxt;
+    ch.beta = 0.0f;
+    ch.gamma = 0.0f;
+    const uint32_t end = S.nslots;   // (the set starts at slot 0: launch_fused only stages sets whose table says so)
+    const float a = dot3(ray.d, ray.d);
+    bool boxed = false, done = false;
+    float cmin = 0.0f, cmax = 0.0f, inv2a = 0.0f;
+    const pt_v4f PT_CONST_AS* p = (const pt_v4f PT_CONST_AS*)S.prims;
+    pt_count(ANY ? PC_SPH_Q_SHADOW : PC_SPH_Q_CLOSEST); pt_count(ANY ? PC_SPH_Q_SHADOW_LANES : PC_SPH_Q_CLOSEST_LANES, true);
+    for (uint32_t c0 = 0u; c0 < end; c0 += 32u) {
+        const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u;
+        uint32_t neg = 0u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float4 sph = ldc4((const void*)p, c0 + i);
+            pt_count(ANY ? PC_SPH_TESTS_SHADOW : PC_SPH_TESTS_CLOSEST);
+            const f3 omc = sub3(ray.o, ld3(sph));
+            const float b = 2.0f * dot3(omc, ray.d);
+            const float c = dot3(omc, omc) - sph.w;
+            const float dis = cl_mad(-4.0f * c, a, b * b);
+            neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(dis), 31);   // (neg << 1) | sign
+        }
+        uint32_t cand = ~neg << (32u - cnt);   // sphere c0 + k at bit 31 - k
+        if (ANY && done) cand = 0u;
+        if (__builtin_amdgcn_ballot_w64(cand != 0u) == 0ull) continue;   // the whole wave misses every sphere of the chunk
+        if (!boxed) {   // wave-uniform: the first chunk with a candidate
+            boxed = true;
+            const BoxHit bh = inter_aabb_t<true, false>(ray, rr, set_box_of(S));
+            cmin = bh.tmin;
+            cmax = bh.v ? cell1_exit(ray, bh, S) : -1.0f;   // a ray that misses the box: an empty window (cmin >= 0)
+            inv2a = rcp_refined(2.0f * a);
+        }
+        while (cand != 0u) {
+            pt_count(ANY ? PC_SPH_ROOTS_SHADOW : PC_SPH_ROOTS_CLOSEST);
+            const uint32_t k = (uint32_t)__builtin_clz(cand);
+            cand &= ~(0x80000000u >> k);
+            const uint32_t i = c0 + k;
+            const float4 sph = *(const float4*)&pt_lds_dyn[S.lds_off + 4u * i];
+            const f3 omc = sub3(ray.o, ld3(sph));
+            const float b = 2.0f * dot3(omc, ray.d);
+            const float c = dot3(omc, omc) - sph.w;
+            const float dis = cl_mad(-4.0f * c, a, b * b);
+            const float sq = cl_sqrt(dis);
+            const float t0 = (-b - sq) * inv2a, t1 = (-b + sq) * inv2a;   // ordered: t0 <= t1 (sph_test, ORDERED)
+            const int in0 = (t0 >= cmin) & (t0 <= cmax), in1 = (t1 >= cmin) & (t1 <= cmax);
+            const float ti = in0 ? t0 : t1;
+            const bool hit = (in0 | in1) != 0;
+            if (ANY && FLAG_ONLY) {
+                if (hit && ti < ray.maxt) { done = true; cand = 0u; }
+                continue;
+            }
+            const bool better = (int)hit & (int)(ti < ch.t);
+            ch.t = better ? ti : ch.t;
+            ch.idx = better ? i : ch.idx;
+            if (ANY && better) { done = true; cand = 0u; }
+        }
+        if (ANY && __builtin_amdgcn_ballot_w64(!done) == 0ull) break;
     }
     if (ANY && FLAG_ONLY && done) ch.idx = 0u;
     return ch;

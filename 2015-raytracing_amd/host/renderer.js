@@ -270,7 +270,9 @@ class FusedRenderer {
     this.seeds = this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 4);
     if (opt.seeds) this.q.enqueueWriteBuffer(this.seeds, false, 0, this.nrays * 4, opt.seeds.subarray(first, first + this.nrays), []);
     else this.q.seedFill(this.seeds, first, this.nrays, opt.seedBase || 0);
-    this.acu = this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 16);   // not zeroed: the first pass initialises it (firstPass below)
+    // not zeroed: the first pass initialises it (firstPass below).  opt.keepAcu === false: a one-pass frame without the 16 bytes per ray -- the pass
+    // resolves its pixels itself (mirt_render_first_pass with acu == NULL: rays_per_pixel must divide 256, and there is no second pass)
+    this.acu = opt.keepAcu === false ? null : this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 16);
     this.pixel = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, this.npix * 4);
     this.radiance = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, this.npix * 16);
     this.passes = 1;
@@ -288,7 +290,7 @@ class FusedRenderer {
   readRadiance() { const o = new Float32Array(this.npix * 4); this.q.enqueueReadBuffer(this.radiance, false, 0, o.byteLength, o, []); this.q.finish(); return o; }
   readAcu() { const a = new Float32Array(this.nrays * 4); this.q.enqueueReadBuffer(this.acu, false, 0, a.byteLength, a, []); this.q.finish(); return a; }
   release() {
-    [this.seeds, this.acu, this.pixel, this.radiance].forEach((b) => b.release());
+    [this.seeds, this.acu, this.pixel, this.radiance].forEach((b) => b && b.release());
     this.dev.bufs.forEach((b) => b.release());
     this.q.release();
     if (this.ownCtx) this.ctx.release();

@@ -162,7 +162,7 @@ class WebCLCommandQueue {
                             cellOffsets: s.cellOffsets.h, bounds: s.bounds, nSlabs: s.nSlabs, meshMatId: s.meshMatId || 0 };
     const d = Object.assign({}, desc, {
       spheres: g(desc.spheres), triangles: g(desc.triangles), meshes: (desc.meshes || []).map(g),
-      material: desc.material.h, seeds: desc.seeds.h, acu: desc.acu.h,
+      material: desc.material.h, seeds: desc.seeds.h, acu: desc.acu ? desc.acu.h : undefined,   // no acu: a first pass that resolves its pixels itself (mirt.h)
       pixel: desc.pixel ? desc.pixel.h : undefined, radiance: desc.radiance ? desc.radiance.h : undefined,
     });
     wrap(() => native().renderPass(this.ctx.h, d));

@@ -104,6 +104,7 @@ SYMBOLS = {
     "mirt_capture_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mirt_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mirt_graph_release": (C.c_int, [C.c_void_p]),
+    "mirt_debug_prepared": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mirt_debug_numerics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mirt_buf_invalidate": (C.c_int, [C.c_void_p]),
     "mirt_mesh_ingest": (C.c_int, [C.c_void_p, C.POINTER(_MeshIngestDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -125,6 +126,8 @@ def lib():
             raise MirtError(-7, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("MIRT_LIB_PATH") and not hasattr(l, name):
+                continue   # an A/B build of an older tree (profiles/ab.sh): it lacks the newer entry points, which its runs do not call
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
@@ -376,6 +379,14 @@ class Context:
         out.release()
         return r
 
+    def prepared(self, positions, count):
+        """the runtime's prepared copy of a triangle position buffer (records, group spheres, plane list) as bytes"""
+        total = C.c_size_t(0)
+        self._chk(lib().mirt_debug_prepared(self.h, positions.h, count, None, 0, C.byref(total)))
+        out = np.zeros(total.value, np.uint8)
+        self._chk(lib().mirt_debug_prepared(self.h, positions.h, count, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(total)))
+        return out
+
     def render_pass(self, desc, fresh=False):
         """fresh: the frame's first pass with initAcu folded in (mirt_render_first_pass): acu is not read."""
         f = lib().mirt_render_first_pass if fresh else lib().mirt_render_pass
@@ -451,7 +462,7 @@ class DeviceScene:
         d.lights = C.cast(larr, C.POINTER(_Light))
         d.n_lights = len(s.lights)
         d.material = self.material.h
-        d.seeds, d.acu = seeds.h, acu.h
+        d.seeds, d.acu = seeds.h, (acu.h if acu else None)   # acu None: a frame's first pass that resolves its pixels itself (include/mirt.h)
         d.pixel = pixel.h if pixel else None
         d.radiance = radiance.h if radiance else None
         d._keep = keep

@@ -198,9 +198,11 @@ class GranularRenderer:
 class FusedRenderer:
     """One mirt_render_pass per progressive pass over rows [row0, row0+nrows)."""
 
-    def __init__(self, ctx, scene, seeds=None, seed_base=0, row0=0, nrows=None, want_radiance=True):
+    def __init__(self, ctx, scene, seeds=None, seed_base=0, row0=0, nrows=None, want_radiance=True, keep_acu=True):
         """nrows None: the whole image from row0 = 0.  nrows == 0 is an EMPTY tile (more ranks than rows): it owns minimal buffers and
-        its passes do nothing -- it is not the whole frame."""
+        its passes do nothing -- it is not the whole frame.
+        keep_acu False: no per-ray accumulator at all (16 B per ray never allocated); only a frame's first pass can then run, with
+        rays_per_pixel dividing 256: the pass resolves its pixels itself (mirt_render_first_pass with acu == NULL)."""
         self.ctx, self.s = ctx, scene
         self.dev = mirt.DeviceScene(ctx, scene)
         self.row0 = row0
@@ -214,8 +216,10 @@ class FusedRenderer:
                 self.seeds.write(np.asarray(seeds, np.int32)[self.first_ray:self.first_ray + self.nrays])
             else:
                 ctx.seed_fill(self.seeds, self.first_ray, self.nrays, seed_base)
-        self.acu = ctx.buffer(self.nrays * 16 or 16)
-        ctx.zero(self.acu)
+        self.acu = None
+        if keep_acu:
+            self.acu = ctx.buffer(self.nrays * 16 or 16)
+            ctx.zero(self.acu)
         self.pixel = ctx.buffer(self.npix * 4 or 16)
         self.radiance = ctx.buffer(self.npix * 16 or 16) if want_radiance else None
         self.passes = 1

@@ -40,8 +40,9 @@ FLOPS_PER_SAMPLE = {"cornell": {5: 6612.3, 8: 9788.3}, "cornell_teapot3": {5: 10
 SCENE_FIXTURE = {"cornell_teapot3": "cornell_teapot3_32x24_r4", "cornell_official": "cornell_official_64x48_r1", "basic": "basic_32x24_r4",
                  "triangles": "triangles_32x24_r4", "twoLights": "twoLights_32x24_r4", "threeLights": "threeLights_32x24_r1",
                  "own_gems": "own_gems_48x36_r4", "own_studio": "own_studio_48x36_r4", "own_flat": "own_flat_32x24_r4"}
-BYTES_PER_SAMPLE_FUSED = 24.0       # seed 4 in + 4 out, accumulator 16 out (a frame's first pass does not read it)
-BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0
+BYTES_PER_SAMPLE_SEED = 8.0         # seed 4 in + 4 out: all a sample moves when the pass resolves its pixels itself
+BYTES_PER_SAMPLE_ACU = 16.0         # + the per-ray accumulator written (--keep-acu, or a ray count that does not divide 256)
+BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0   # RGBA8 + the fp32 radiance sums
 PEAK_VALU_TFLOPS = 157.3            # MI355X_MICROARCH.md: peak FP32 vector (FMA-counted)
 PEAK_HBM_GBS = 8000.0
 SIMDS, NOMINAL_HZ, MEASURED_ISSUE_CYCLES = 1024, 2.4e9, 2.4   # profiles/micro/valu_rate.hip: cycles per plain fp32 VOP2 wave-instruction at 8 waves (spec: 2)
@@ -163,6 +164,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--no-depth5", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--keep-acu", action="store_true", help="keep the 16-byte per-ray accumulator (what a progressive second pass needs); default: the one-pass "
+                    "frame without it -- the pass resolves its pixels itself, 8 B per sample + 20 B per pixel (SURVEY 8d)")
     ap.add_argument("--pmc-summary", default=None, help="pmc_summary.json of a rocprofv3 run of this command (profiles/run_profile.sh); default: the "
                     "newest one under profiles/ stamped with this source tree and workload.  Without one, `traffic` and `issue` are null")
     args = ap.parse_args()
@@ -222,7 +225,8 @@ def main():
     ctx.set_profiling(True)
     if os.environ.get("MIRT_EXACT_ONLY") == "1":   # A/B knob: the single exact kernel instead of the default optimistic pair
         ctx.set_exact_only(True)
-    fr = render.FusedRenderer(ctx, sc, row0=row0, nrows=nrows, want_radiance=True)
+    no_acu = not (args.keep_acu or os.environ.get("BENCH_KEEP_ACU") == "1") and 256 % sc.rpp == 0 and os.environ.get("MIRT_INPASS_RESOLVE", "1") != "0"
+    fr = render.FusedRenderer(ctx, sc, row0=row0, nrows=nrows, want_radiance=True, keep_acu=not no_acu)
     # the RGBA8 tile lives in a torch tensor so RCCL can move it
     tile = torch.zeros(max_rows * sc.width * 4, dtype=torch.uint8, device="cuda")
     fr.pixel.release()
@@ -270,7 +274,8 @@ def main():
     has_grids = any(m["nslabs"] > 1 for m in sc.d.get("meshes", [])) or sc.d.get("n_slabs", 1) > 1
     # <optimistic, grids: 0 none / 1 tables in LDS / 2 in memory, waves: 0 the default build / 5 the grid kernels' 5-wave build>; matched as a prefix
     kernel_name = "pt::k_fusedPass<true,1," if has_grids else "pt::k_fusedPass<true,0,"
-    hbm_gbs = BYTES_PER_SAMPLE_FUSED * local_samples / (fused_ms * 1e-3) / 1e9
+    bytes_per_sample = BYTES_PER_SAMPLE_SEED + (BYTES_PER_PIXEL_RESOLVE / sc.rpp if no_acu else BYTES_PER_SAMPLE_ACU)
+    hbm_gbs = bytes_per_sample * local_samples / (fused_ms * 1e-3) / 1e9
 
     # counters: only what a named rocprofv3 summary of this build and workload holds (FETCH_SIZE / WRITE_SIZE in KiB, separate passes;
     # gfx950 halves FETCH_SIZE on wide coalesced reads: MI355X_MICROARCH.md)
@@ -306,10 +311,10 @@ def main():
             "source": pmc_path + ", profiles/micro/README.md"},
         "roofline_hbm": {"kernel": kernel_name, "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 5), "traffic": traffic,
-                         "traffic_note": (f"algorithmic {BYTES_PER_SAMPLE_FUSED * local_samples / 1e9:.2f} GB/launch (seeds in + out, accumulator out); measured "
+                         "traffic_note": (f"algorithmic {bytes_per_sample * local_samples / 1e9:.2f} GB/launch (seeds in + out, " + ("RGBA8 + radiance per pixel" if no_acu else "accumulator out") + "); measured "
                                           f"{fetch * 2 * 1024 / 1e9:.2f} + {write * 1024 / 1e9:.2f} GB (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes, {pmc_path})") if traffic is not None
                                          else f"no counters: {pmc if not pmc_path else 'summary lacks FETCH_SIZE / WRITE_SIZE'}",
-                         "bytes_per_sample": BYTES_PER_SAMPLE_FUSED},
+                         "bytes_per_sample": round(bytes_per_sample, 3), "resolve": "in the pass (no per-ray accumulator)" if no_acu else "separate copyToPixel over acu"},
         "build": {"csrc_sha256": csrc_sha256()[:16]},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

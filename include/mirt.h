@@ -272,6 +272,12 @@ MIRT_API int mirt_grid_gather_u32(mirt_ctx* ctx, mirt_buf* order, uint32_t total
  * Lets a test compare device bits with AMD's OpenCL library (oracle/probe/builtins.cl) over millions of inputs. ---- */
 MIRT_API int mirt_debug_numerics(mirt_ctx* ctx, int op, mirt_buf* a, mirt_buf* b, mirt_buf* out, size_t n);
 
+/* the PREPARED copy the runtime keeps of a triangle position buffer holding `count` triangles (3 x float4 each), built on first use by a pass
+ * or frame kernel and rebuilt when the buffer's contents change: `count` records of 48 bytes {p0, n.x}{e1, n.y}{e2, n.z}, one bounding sphere
+ * (float4) per 16 records, and -- for at most 96 records -- the candidate sweep's plane list (64-byte aligned; csrc/pt_launch.hpp).  Copies up
+ * to `bytes` of it to `out` and reports its size in *total.  For the tests that pin its layout against the CPU restatement. */
+MIRT_API int mirt_debug_prepared(mirt_ctx* ctx, mirt_buf* positions, uint32_t count, void* out, size_t bytes, size_t* total);
+
 /* counts mismatches between the shared-reciprocal division forms of pt_numerics.hpp and the compiler's correctly
  * rounded division over `count` generated (n, d) pairs; `out16` receives 16 uint64 (see k_divCheck).
  * mode 0/1/2: random pairs inside the windows; 3: all 2^32 denominators of the reciprocal; 4: every numerator mantissa

@@ -1,7 +1,8 @@
 /* oracle/sweep_check.c -- TEST INFRASTRUCTURE (part of liboracle.so; the product never links it).
  *
- * A CPU restatement of the candidate sweep's PLANE WINDOW (2015-raytracing_amd/csrc/pt_trace.hpp trace_cell1, LANES; the constants of
- * k_planeRuns in pt_kernels_fused.hip) beside the reference's interTriangle (A10 code.cl:250-288) under the numerics contract of
+ * A CPU restatement of the candidate sweep's PLANE WINDOW (2015-raytracing_amd/csrc/pt_trace.hpp trace_cell1, LANES; the plane list of
+ * k_planeList in pt_kernels_fused.hip: general planes, AXIS planes, and the BACK verdict of a plane listed with the reversed normal)
+ * beside the reference's interTriangle (A10 code.cl:250-288) under the numerics contract of
  * cl_numerics.h, to check the one claim the product's speed-up rests on:
  *
  *      the sweep drops a triangle  ==>  the reference's own test rejects it  (for the window the caller compares t with)
@@ -11,8 +12,13 @@
  * forty octaves, needle triangles, near-parallel rays -- and counts the violations (dropped by the sweep, accepted by the reference).
  * tests/test_sweep_filter.py asserts the count is zero and that the sweep still drops most of what the reference rejects (it is a
  * filter, not a constant `true`).  The margin's derivation is in pt_trace.hpp; this is its empirical side, runnable without a GPU.
- * The margin checked is each triangle's OWN (G, H); the kernel gives every plane of a 32-record chunk the chunk's largest pair
- * (PT_SWEEP_UNIFORM_MARGIN), which keeps a superset of what is kept here: the check is on the tightest margin the product can use. */
+ * The margin checked is each triangle's OWN (G, H); the kernel gives every plane of a 32-record chunk the chunk's largest pair,
+ * which keeps a superset of what is kept here: the check is on the tightest margin the product can use.
+ *
+ * Second half (oracle_plane_list, oracle_sweep_words): the LAYOUT the kernel consumes -- k_planeList restated word for word (classes, merged
+ * masks, back masks, 64-byte groups, the chunk's largest margins) and the sweep's walk over it, so tests/test_sweep_filter.py can check on the
+ * CPU that candidate bit 31 - j of chunk c is record 32 c + j and that every record sits in exactly one mask, and tests/test_gpu_parity.py that
+ * the device builds the same bytes (mirt_debug_prepared). */
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -57,26 +63,63 @@ static float ref_t(v3 o, v3 d, v3 p0, v3 e1, v3 e2) {
     return v3dot(v3cross(s, e2), e1) * -(1.0f / div);
 }
 
-/* k_planeRuns: the plane entry of one record */
-static void plane_entry(v3 p0, v3 e1, v3 e2, v3* n, float* k, float* G, float* H) {
+/* k_planeList: the margin constants of one record */
+static void plane_margin(v3 p0, v3 e1, v3 e2, float* G, float* H) {
     const float up = 1.0000002384185791015625f;
-    *n = v3cross(e2, e1);
-    *k = (float)((double)p0.x * n->x + (double)p0.y * n->y + (double)p0.z * n->z);
     const float E = ((l1(e1)) * up) * ((l1(e2)) * up) * up;
     *G = 0x1p-17f * E;
     *H = fmaxf(*G * (l1(p0) * up) * up, 0x1p-56f);
 }
-/* trace_cell1's sweep verdict: 1 = candidate (sign bit of w clear) */
-static int sweep_keeps(v3 o, v3 d, float cmin, float cmax, float maxt, v3 n, float k, float G, float H) {
+/* k_planeList: the class of a record -- 0 / 1 / 2: an axis plane {x_a = p0_a} (n has two zero components, both edges exactly zero along a);
+ * 3: general */
+static int plane_class(v3 p0, v3 e1, v3 e2, v3 n) {
+    const float nn[3] = {n.x, n.y, n.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+    int cl = 3;
+    (void)p0;
+    for (int a = 0; a < 3; ++a)
+        if (nn[a] != 0.0f && nn[(a + 1) % 3] == 0.0f && nn[(a + 2) % 3] == 0.0f && a1[a] == 0.0f && a2[a] == 0.0f) cl = a;
+    return cl;
+}
+static inline float canon0(float v) { return v == 0.0f ? 0.0f : v; }   /* -0 -> +0, as the list stores a normal's zero components */
+/* trace_cell1's verdicts from a plane's div and sn: 1 = candidate (sign bit of w clear).  front: the records of the entry's mask; back: those
+ * of its back mask (the same plane listed with the reversed normal) */
+static int verdict_front(float div, float sn, float M, float hi_p, float lo_m) {
+    const float sp = sn + M, sm = sn - M;
+    const float w = cln_min(cln_min(div, fmaf(hi_p, div, sp)), -fmaf(lo_m, div, sm));
+    return (cln_bits(w) >> 31) == 0u;
+}
+static int verdict_back(float div, float sn, float M, float hi_p, float lo_m) {
+    const float sp = sn + M, sm = sn - M;
+    const float w = cln_min(cln_min(-div, -fmaf(hi_p, div, sm)), fmaf(lo_m, div, sp));
+    return (cln_bits(w) >> 31) == 0u;
+}
+/* the (div, sn) the sweep computes for an entry: cl < 3: {q, n_a}; cl == 3: {n, k} */
+static void entry_eval(int cl, const float* e, v3 o, v3 d, float* div, float* sn) {
+    if (cl < 3) {
+        const float oa = cl == 0 ? o.x : (cl == 1 ? o.y : o.z), da = cl == 0 ? d.x : (cl == 1 ? d.y : d.z);
+        *div = e[1] * da;
+        *sn = e[1] * (oa - e[0]);
+    } else {
+        *div = cln_dot3(e[0], e[1], e[2], d.x, d.y, d.z);
+        *sn = fmaf(e[2], o.z, fmaf(e[1], o.y, fmaf(e[0], o.x, -e[3])));
+    }
+}
+/* the sweep's verdict on one record through the entry the list would hold for it; reversed: through the entry of its reversed twin (back mask) */
+static int sweep_keeps(v3 o, v3 d, float cmin, float cmax, float maxt, v3 p0, v3 e1, v3 e2, float G, float H, int reversed) {
     const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
     const float hi_p = cln_max(cln_min(cmax, maxt) * 1.00000095367431640625f, 0x1p-100f);
     const float lo_m = cmin * 0.99999904632568359375f;
-    const float div = v3dot(n, d);
-    const float sn = fmaf(n.z, o.z, fmaf(n.y, o.y, fmaf(n.x, o.x, -k)));
+    const v3 n = v3cross(e2, e1);
+    const float k = (float)((double)p0.x * n.x + (double)p0.y * n.y + (double)p0.z * n.z);
+    const int cl = plane_class(p0, e1, e2, n);
+    const float sg = reversed ? -1.0f : 1.0f;   /* the twin's entry: -n, -k (an axis plane keeps its coordinate) */
+    float e[4];
+    if (cl < 3) { e[0] = canon0(cl == 0 ? p0.x : (cl == 1 ? p0.y : p0.z)); e[1] = sg * (cl == 0 ? n.x : (cl == 1 ? n.y : n.z)); e[2] = e[3] = 0.0f; }
+    else { e[0] = canon0(sg * n.x); e[1] = canon0(sg * n.y); e[2] = canon0(sg * n.z); e[3] = canon0(sg * k); }
+    float div, sn;
+    entry_eval(cl, e, o, d, &div, &sn);
     const float M = fmaf(G, o1, H);
-    const float c = fmaf(hi_p, div, sn + M), a = fmaf(lo_m, div, sn - M);
-    const float w = cln_min(cln_min(div, c), -a);
-    return (cln_bits(w) >> 31) == 0u;
+    return reversed ? verdict_back(div, sn, M, hi_p, lo_m) : verdict_front(div, sn, M, hi_p, lo_m);
 }
 
 static inline uint64_t mix64(uint64_t* s) {
@@ -128,9 +171,9 @@ void oracle_sweep_check(uint64_t seed, uint64_t count, int shrink, uint64_t* out
         }
         p0.x *= scale; p0.y *= scale; p0.z *= scale; p1.x *= scale; p1.y *= scale; p1.z *= scale; p2.x *= scale; p2.y *= scale; p2.z *= scale;
         const v3 e1 = v3sub(p1, p0), e2 = v3sub(p2, p0);
-        v3 n;
-        float k, G, H;
-        plane_entry(p0, e1, e2, &n, &k, &G, &H);
+        const v3 n = v3cross(e2, e1);
+        float G, H;
+        plane_margin(p0, e1, e2, &G, &H);
         G = ldexpf(G, -shrink);
         H = ldexpf(H, -shrink);
 
@@ -188,10 +231,110 @@ void oracle_sweep_check(uint64_t seed, uint64_t count, int shrink, uint64_t* out
 
         float t;
         const int accept = ref_test(o, d, cmin, cmax, maxt, p0, e1, e2, &t);
-        const int keep = sweep_keeps(o, d, cmin, cmax, maxt, n, k, G, H);
+        const int keep = sweep_keeps(o, d, cmin, cmax, maxt, p0, e1, e2, G, H, (int)(mix64(&s) & 1u));   /* through its own entry, or its reversed twin's */
         cases++;
         if (accept) { acc++; if (!keep) viol++; }
         else { rej++; if (!keep) dropped++; }
     }
     out[0] = cases; out[1] = viol; out[2] = acc; out[3] = rej; out[4] = dropped; out[5] = skipped;
+}
+
+/* ---- the layout: k_planeList (pt_kernels_fused.hip) word for word.  prep: count records {p0.xyz, n.x} {e1.xyz, n.y} {e2.xyz, n.z} as
+ * k_prepTriangles leaves them; out: the plane list, 16 + 16 * groups words (at most 16 + 4 * 320 words for 96 records); returns the words written */
+uint32_t oracle_plane_list(const float* prep, uint32_t count, uint32_t* out) {
+    uint32_t* hdr = out;
+    uint32_t* ent = out + 16;
+    uint32_t groups = 0;
+    for (uint32_t c = 0; c < 4u; ++c) {
+        const uint32_t lo = c * 32u, hi = lo + 32u < count ? lo + 32u : count;
+        hdr[c] = 0u; hdr[4u + c] = groups; hdr[8u + c] = 0u; hdr[12u + c] = 0u;
+        if (lo >= count) continue;
+        float gmax = 0.0f, hmax = 0.0f;
+        uint32_t cls[32], key[32][4];
+        for (uint32_t i = lo; i < hi; ++i) {
+            const float* r = prep + 12u * i;
+            const v3 p0 = {r[0], r[1], r[2]}, e1 = {r[4], r[5], r[6]}, e2 = {r[8], r[9], r[10]}, n = {r[3], r[7], r[11]};
+            const float k = (float)((double)p0.x * n.x + (double)p0.y * n.y + (double)p0.z * n.z);
+            float G, H;
+            plane_margin(p0, e1, e2, &G, &H);
+            gmax = fmaxf(gmax, G); hmax = fmaxf(hmax, H);
+            const int cl = plane_class(p0, e1, e2, n);
+            cls[i - lo] = (uint32_t)cl;
+            const float nn[3] = {n.x, n.y, n.z}, pp[3] = {p0.x, p0.y, p0.z};
+            if (cl < 3) { key[i - lo][0] = cln_bits(canon0(pp[cl])); key[i - lo][1] = cln_bits(nn[cl]); key[i - lo][2] = key[i - lo][3] = 0u; }
+            else { key[i - lo][0] = cln_bits(canon0(n.x)); key[i - lo][1] = cln_bits(canon0(n.y)); key[i - lo][2] = cln_bits(canon0(n.z)); key[i - lo][3] = cln_bits(canon0(k)); }
+        }
+        hdr[8u + c] = cln_bits(gmax); hdr[12u + c] = cln_bits(hmax);
+        uint32_t packed = 0u;
+        for (uint32_t cl = 0; cl < 4u; ++cl) {
+            const uint32_t per = cl < 3u ? 4u : 2u, words = cl < 3u ? 4u : 8u;
+            uint32_t n_ent = 0, done = 0u;
+            uint32_t* base = ent + 16u * groups;
+            for (uint32_t i = 0; i < hi - lo; ++i) {
+                if (cls[i] != cl || (done >> i & 1u)) continue;
+                uint32_t mask = 0u, back = 0u;
+                for (uint32_t j = i; j < hi - lo; ++j) {
+                    if (cls[j] != cl || (done >> j & 1u)) continue;
+                    int same = 1, rev = 1;
+                    for (uint32_t w = 0; w < 4u; ++w) {
+                        const uint32_t a = key[i][w], b = key[j][w];
+                        same = same && a == b;
+                        const int coord = cl < 3u && w == 0u;
+                        rev = rev && ((coord || a == 0u) ? a == b : (a ^ 0x80000000u) == b);
+                    }
+                    if (same) { mask |= 0x80000000u >> j; done |= 1u << j; }
+                    else if (rev) { back |= 0x80000000u >> j; done |= 1u << j; }
+                }
+                uint32_t* e = base + words * n_ent;
+                for (uint32_t w = 0; w < words; ++w) e[w] = 0u;
+                if (cl < 3u) { e[0] = key[i][0]; e[1] = key[i][1]; e[2] = mask; e[3] = back; }
+                else { e[0] = key[i][0]; e[1] = key[i][1]; e[2] = key[i][2]; e[3] = key[i][3]; e[4] = mask; e[5] = back; }
+                ++n_ent;
+            }
+            const uint32_t g = (n_ent + per - 1u) / per;
+            for (uint32_t w = words * n_ent; w < 16u * g; ++w) base[w] = 0u;
+            packed |= g << (8u * cl);
+            groups += g;
+        }
+        hdr[c] = packed;
+    }
+    return 16u + 16u * groups;
+}
+
+/* trace_cell1's sweep over the list for one ray: cand[c] = the candidate word of chunk c (record 32 c + j at bit 31 - j) */
+void oracle_sweep_words(const uint32_t* list, uint32_t count, const float* o3, const float* d3, float cmin, float cmax, float maxt, uint32_t* cand) {
+    const v3 o = {o3[0], o3[1], o3[2]}, d = {d3[0], d3[1], d3[2]};
+    const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
+    const float hi_p = cln_max(cln_min(cmax, maxt) * 1.00000095367431640625f, 0x1p-100f);
+    const float lo_m = cmin * 0.99999904632568359375f;
+    for (uint32_t c0 = 0, c = 0; c0 < count; c0 += 32u, ++c) {
+        const uint32_t groups = list[c];
+        const uint32_t* g = list + 16 + 16u * list[4u + c];
+        const float Mu = fmaf(cln_float(list[8u + c]), o1, cln_float(list[12u + c]));
+        uint32_t w = 0u;
+        for (uint32_t cl = 0; cl < 4u; ++cl) {
+            const uint32_t ng = (groups >> (8u * cl)) & 255u, per = cl < 3u ? 4u : 2u, words = cl < 3u ? 4u : 8u;
+            for (uint32_t i = 0; i < ng; ++i, g += 16) {
+                for (uint32_t k = 0; k < per; ++k) {
+                    const uint32_t* e = g + words * k;
+                    const uint32_t mask = cl < 3u ? e[2] : e[4], back = cl < 3u ? e[3] : e[5];
+                    if ((mask | back) == 0u) continue;
+                    float ef[4] = {cln_float(e[0]), cln_float(e[1]), cln_float(e[2]), cln_float(e[3])};
+                    float div, sn;
+                    entry_eval((int)cl, ef, o, d, &div, &sn);
+                    if (verdict_front(div, sn, Mu, hi_p, lo_m)) w |= mask;
+                    if (back != 0u && verdict_back(div, sn, Mu, hi_p, lo_m)) w |= back;
+                }
+            }
+        }
+        cand[c] = w;
+    }
+}
+
+/* the reference's verdict on record i of `prep` for the same ray and window (what a dropped candidate must not be) */
+int oracle_sweep_ref_accepts(const float* prep, uint32_t i, const float* o3, const float* d3, float cmin, float cmax, float maxt) {
+    const float* r = prep + 12u * i;
+    const v3 o = {o3[0], o3[1], o3[2]}, d = {d3[0], d3[1], d3[2]}, p0 = {r[0], r[1], r[2]}, e1 = {r[4], r[5], r[6]}, e2 = {r[8], r[9], r[10]};
+    float t;
+    return ref_test(o, d, cmin, cmax, maxt, p0, e1, e2, &t);
 }

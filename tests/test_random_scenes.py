@@ -111,7 +111,7 @@ def test_random_scene_all_paths_agree(ctx, pkg, seed):
     gr.release()
 
 
-def quad_scene(base, seed, n_tris):
+def quad_scene(base, seed, n_tris, two_sided=0.0, shuffle=False):
     """Loose triangles that come in coplanar PAIRS (the halves of rectangles, same winding: bit-identical plane normals where the
     arithmetic is exact, nearly identical elsewhere), as scenes built from quads have them; an odd count leaves a single at the end.
     Sizes around the 32-record chunks of the candidate sweep, so a pair straddles a chunk boundary (records 31 | 32, 63 | 64)."""
@@ -137,11 +137,17 @@ def quad_scene(base, seed, n_tris):
         p = [c, c + u, c + u + w, c + w]
         n = np.cross(w, u)
         n = n / (np.linalg.norm(n) + 1e-30)
-        for tri in ((p[0], p[1], p[2]), (p[0], p[2], p[3])):
+        quad = [((p[0], p[1], p[2]), n), ((p[0], p[2], p[3]), n)]
+        if rng.random() < two_sided:   # the same two triangles again with the winding reversed: the back faces (the plane list's back masks)
+            quad += [((a, c2, b), -n) for (a, b, c2), _ in quad]
+        for tri, nn in quad:
             if k < n_tris:
                 v[k] = np.asarray(tri, np.float32)
-                nrm[k] = n.astype(np.float32)
+                nrm[k] = nn.astype(np.float32)
                 k += 1
+    if shuffle:   # the halves of a quad and the twins anywhere in the list: merged through the entry masks, not through adjacency
+        perm = rng.permutation(n_tris)
+        v, nrm = v[perm], nrm[perm]
     b8 = _bbox8(v.reshape(-1, 3).min(axis=0) - 0.01, v.reshape(-1, 3).max(axis=0) + 0.01)
     off, order = expected_grid(1, v.reshape(n_tris, 9).astype(np.float64), [b8[0], b8[1], b8[2], b8[4], b8[5], b8[6]], 1)
     assert np.array_equal(order, np.arange(n_tris))      # one cell: upload order kept, pairs stay adjacent
@@ -152,13 +158,16 @@ def quad_scene(base, seed, n_tris):
     return _variant(base, width=64, height=36, rays_per_pixel=4, **out)
 
 
+@pytest.mark.parametrize("variant", ["pairs", "two_sided_shuffled"])
 @pytest.mark.parametrize("n_tris", [2, 12, 31, 33, 63, 65, 95, 96, 97])
-def test_quad_soups_through_the_plane_runs(ctx, pkg, n_tris):
-    """The candidate sweep's plane list (k_planeRuns): runs of two records in one plane, chunk boundaries inside a pair, the last
-    staged size (96) and the first that falls back to the wave-uniform loop (97) -- optimistic pair == exact kernel == CPU oracle."""
+def test_quad_soups_through_the_plane_list(ctx, pkg, n_tris, variant):
+    """The candidate sweep's plane list (k_planeList): records merged per plane through masks (adjacent halves of a quad; with
+    `two_sided_shuffled` the halves anywhere in the list and back faces in the back masks), axis planes and general ones, chunk boundaries
+    inside a pair, the last staged size (96) and the first that falls back to the wave-uniform loop (97) -- optimistic pair == exact
+    kernel == CPU oracle."""
     from raytracing_amd.pyhost import render
     _, base = load_fixture("cornell_32x24_r4")
-    sc = quad_scene(base, 77 + n_tris, n_tris)
+    sc = quad_scene(base, 77 + n_tris, n_tris) if variant == "pairs" else quad_scene(base, 177 + n_tris, n_tris, two_sided=0.4, shuffle=True)
     seeds = A.make_seeds(sc.total_rays, seed_base=n_tris)
     st = A.PassState(sc, seeds)
     A.run_pass(A.load_oracle(), sc, st, bounces=8)
@@ -171,3 +180,28 @@ def test_quad_soups_through_the_plane_runs(ctx, pkg, n_tris):
         fr.release()
     ctx.set_exact_only(False)
     assert (st.acu[:, 3] > 0).any()       # the soup is hit
+
+
+@pytest.mark.parametrize("n_tris", [1, 12, 32, 33, 64, 96])
+def test_device_plane_list_equals_the_cpu_restatement(ctx, pkg, n_tris):
+    """k_planeList on the device against oracle/sweep_check.c's word-for-word restatement, fed the device's own prepared records: header,
+    classes, masks, back masks, padding, the chunks' largest margin constants -- byte for byte.  (The restatement's layout properties and the
+    soundness of the sweep over it are CPU tests: tests/test_sweep_filter.py.)"""
+    import ctypes as C
+    import os
+    from conftest import ROOT
+    _, base = load_fixture("cornell_32x24_r4")
+    sc = quad_scene(base, 500 + n_tris, n_tris, two_sided=0.4, shuffle=True)
+    pos = ctx.buffer_from(np.asarray(sc.t_pos, np.float32))
+    raw = ctx.prepared(pos, n_tris)
+    pos.release()
+    rec = raw[:48 * n_tris].view(np.float32).copy()
+    off = (48 * n_tris + (n_tris + 15) // 16 * 16 + 63) & ~63          # pt_launch.hpp prepared_planes_offset
+    dev = raw[off:].view(np.uint32)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    lib.oracle_plane_list.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.oracle_plane_list.restype = C.c_uint32
+    cpu = np.zeros(16 + 4 * 320, np.uint32)
+    used = lib.oracle_plane_list(rec.ctypes.data, n_tris, cpu.ctypes.data)
+    assert used <= dev.size
+    assert np.array_equal(dev[:used], cpu[:used])
