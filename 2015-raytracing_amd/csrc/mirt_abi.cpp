@@ -474,6 +474,9 @@ struct mirt_group {
     std::vector<mirt_ctx*> ctxs;
     std::vector<void*> comms;    // ncclComm_t per device; empty until a gather needs RCCL
     bool repeated_devices = false;   // rehearsal group (MIRT_GROUP_ALLOW_REPEATED_DEVICES): several contexts on one device
+    std::vector<uint8_t> peer;   // [i * n + j]: context i's device reads context j's device's memory directly (hipDeviceEnablePeerAccess succeeded; 1 on the diagonal
+                                 // and between contexts that share a device)
+    std::vector<int> route;      // per tile, how the last mirt_gather moved it (MIRT_ROUTE_*)
 };
 
 static bool live_group(const mirt_group* g) { return live_is(g, H_GROUP); }
@@ -514,10 +517,40 @@ int mirt_group_create(const int* device_ids, int n, mirt_group** out) try {
         c->group = g;
         g->ctxs.push_back(c);
     }
+    // peer access both ways between every pair of distinct devices: what makes hipMemcpyPeerAsync (the copy transport of mirt_gather) a direct xGMI
+    // transfer instead of a bounce through host memory.  A pair the runtime refuses stays 0 and its copies are reported as MIRT_ROUTE_STAGED.
+    g->peer.assign((size_t)n * n, 0);
+    g->route.assign((size_t)n, MIRT_ROUTE_NONE);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int di = g->ctxs[i]->device, dj = g->ctxs[j]->device;
+            if (di == dj) { g->peer[(size_t)i * n + j] = 1; continue; }
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+            if (hipSetDevice(di) != hipSuccess) { (void)hipGetLastError(); continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(dj, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) g->peer[(size_t)i * n + j] = 1;
+            (void)hipGetLastError();
+        }
     live_add(g, H_GROUP);
     *out = g;
     return MIRT_OK;
 } MIRT_CATCH("mirt_group_create", return MIRT_E_DEVICE)
+
+int mirt_group_peer_access(const mirt_group* g, int i, int j) try {
+    if (!live_group(g)) return MIRT_E_HANDLE;
+    const int n = (int)g->ctxs.size();
+    if (i < 0 || j < 0 || i >= n || j >= n) return MIRT_E_ARG;
+    return g->peer[(size_t)i * n + j];
+} MIRT_CATCH("mirt_group_peer_access", return MIRT_E_DEVICE)
+
+int mirt_gather_route(const mirt_group* g, int tile) try {
+    if (!live_group(g)) return MIRT_E_HANDLE;
+    if (tile < 0 || tile >= (int)g->route.size()) return MIRT_E_ARG;
+    return g->route[(size_t)tile];
+} MIRT_CATCH("mirt_gather_route", return MIRT_E_DEVICE)
+
+int mirt_abi_version(void) { return MIRT_ABI_VERSION; }
 
 int mirt_group_size(const mirt_group* g) try { return live_group(g) ? (int)g->ctxs.size() : MIRT_E_HANDLE; } MIRT_CATCH("mirt_group_size", return MIRT_E_DEVICE)
 
@@ -591,7 +624,8 @@ int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes,
                 }
                 if (c->device == rootc->device) HIPCHK(rootc, hipMemcpyAsync((char*)out->ptr + off, tiles[i]->ptr, tile_bytes[i], hipMemcpyDeviceToDevice, rootc->stream));
                 else HIPCHK(rootc, hipMemcpyPeerAsync((char*)out->ptr + off, rootc->device, tiles[i]->ptr, c->device, tile_bytes[i], rootc->stream));
-            }
+                g->route[(size_t)i] = c->device == rootc->device ? MIRT_ROUTE_LOCAL : (g->peer[(size_t)root * n + i] ? MIRT_ROUTE_PEER : MIRT_ROUTE_STAGED);
+            } else g->route[(size_t)i] = MIRT_ROUTE_NONE;
             off += tile_bytes[i];
         }
         out->version++;
@@ -617,6 +651,7 @@ int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes,
     (void)hipSetDevice(rootc->device);
     if (nrc == 0) nrc = erc;
     if (nrc != 0) return fail(rc_ctx, MIRT_E_DEVICE, "mirt_gather: RCCL: %s", R.GetErrorString(nrc));
+    for (int i = 0; i < n; ++i) g->route[(size_t)i] = tile_bytes[i] ? MIRT_ROUTE_RCCL : MIRT_ROUTE_NONE;
     out->version++;
     return MIRT_OK;
 } MIRT_CATCH("mirt_gather", return MIRT_E_DEVICE)

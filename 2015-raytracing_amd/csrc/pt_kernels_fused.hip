@@ -199,9 +199,7 @@ struct ParkT {
 typedef ParkT<256, true> Park;
 
 PT_DEV Box set_box(const GridArgs& S) { return set_box_of(S); }
-#ifndef PT_SPHERE_LISTS
-#define PT_SPHERE_LISTS 1   // optimistic kernel: a staged single-cell sphere set through per-lane candidates (pt_trace.hpp trace_spheres1)
-#endif
+
 
 // closest hit over every set in upload order, z-buffered through ray.maxt
 // (A10 code.cl:675-800, 802-935, 937-1070; order A10 code.js:1809-1813)
@@ -215,9 +213,7 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const PARK& park
         Hit ch;
         ch.idx = UINT32_MAX;
         if (!GRIDS || S.n == 1u) {
-            if (PT_SPHERE_LISTS && PT_LANE_LISTS_FOR(FAST, GRIDS) && S.kind == KIND_SPHERES && S.lds_off != kNoLds) {   // wave-uniform (kernel arguments)
-                if (live) ch = trace_spheres1<false, false>(ray, rr, S);
-            } else if (live) {
+            if (live) {
                 pt_count(PC_BOX_TESTS); pt_count(PC_BOX_LANES, true);
                 const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(ray, rr, set_box(S));
                 if (bh.v) ch = (S.kind == KIND_SPHERES) ? trace_cell1<SPHERES, false, TRI_A10, FAST>(ray, bh, S) : trace_cell1<TRIANGLES, false, TRI_A10, FAST, false, PT_LANE_LISTS_FOR(FAST, GRIDS)>(ray, bh, S);
@@ -300,9 +296,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
             Hit ch;
             bool walked = false;
             if (!GRIDS || S.n == 1u) {
-                if (PT_SPHERE_LISTS && PT_LANE_LISTS_FOR(FAST, GRIDS) && S.kind == KIND_SPHERES && S.lds_off != kNoLds) {
-                    if (live) { ch = trace_spheres1<true, true>(sh, rr, S); walked = true; }
-                } else if (live) {
+                if (live) {
                     pt_count(PC_BOX_TESTS); pt_count(PC_BOX_LANES, true);
                     const BoxHit bh = inter_aabb_t<FAST, !PT_AABB_UNSIGNED_ZERO>(sh, rr, set_box(S));
                     if (bh.v) {
@@ -351,9 +345,16 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
 // every lane walking it to its own i and j it cost up to 2 (k - 1) dependent additions per sample: 30 of them at 256 rays per pixel, 62 at
 // 1024).  k > kLensTab: the lanes walk.
 constexpr uint32_t kLensTab = 64;
+static_assert(kLensTab % 4u == 0u, "the static LDS ahead of pt_lds_dyn stays a multiple of 16 bytes");
 __shared__ float pt_lens_tab[kLensTab];
 __shared__ uint32_t pt_blk_defer[4];   // in-pass resolve: "a sample of this block left the guard windows" (word 0; four words keep what follows 16-byte aligned)
-PT_DEV uint32_t lens_side(const FusedArgs& A) { return f2u_uniform(cl_sqrt((float)A.rpp)); }
+// (the ray count is laundered through an SGPR: as a common subexpression of the block prologue and of every sample's set-up, the float made from it
+// stayed alive in a VGPR between the two -- the one register the 64-register build had to spill)
+PT_DEV uint32_t lens_side(const FusedArgs& A) {
+    uint32_t rpp = A.rpp;
+    asm volatile("" : "+s"(rpp));
+    return f2u_uniform(cl_sqrt((float)rpp));
+}
 
 template <bool FAST, int GRIDS>
 PT_DEV void stage_block(const FusedArgs& A) {
@@ -371,11 +372,7 @@ PT_DEV void stage_block(const FusedArgs& A) {
         for (uint32_t s = 0; s < A.n_sets; ++s) {
             const GridArgs& S = A.sets[s];
             if (S.lds_off == kNoLds) continue;
-            if (S.n == 1u && S.kind == KIND_SPHERES) {
-                if (!(PT_SPHERE_LISTS && PT_LANE_LISTS_FOR(FAST, GRIDS))) continue;
-                const uint32_t* src = (const uint32_t*)S.prims;   // float4 (c, r^2) per sphere
-                for (uint32_t k = threadIdx.x; k < S.nslots * 4u; k += 256u) pt_lds_dyn[S.lds_off + k] = src[k];
-            } else if (S.n == 1u) {
+            if (S.n == 1u) {
                 if (!PT_LANE_LISTS_FOR(FAST, GRIDS)) continue;
                 // [records 12 words each][vertex normals 12 words each][material ids, one word each: a mesh's single id repeated]
                 const uint32_t words = S.nslots * 12u;
@@ -397,8 +394,10 @@ PT_DEV void stage_block(const FusedArgs& A) {
 // initTrace (code.cl:458-543) for one ray id of the tile: thin-lens ray through its pixel, clipped to the scene box
 // (tile-local ray ids fit 32 bits: mirt_render_pass refuses a tile of more than 2^32 - 256 rays)
 PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
-    const uint32_t lpix = lid / A.rpp;
-    const uint32_t smp = lid - lpix * A.rpp;
+    // (the host makes rays_per_pixel k x k; when k is a power of two -- 1, 4, 16, 64, 256, 1024 -- the pixel and the sample are a shift and a mask)
+    const bool pow2 = (A.rpp & (A.rpp - 1u)) == 0u;   // wave-uniform
+    const uint32_t lpix = pow2 ? lid >> (uint32_t)__builtin_ctz(A.rpp) : lid / A.rpp;
+    const uint32_t smp = pow2 ? lid & (A.rpp - 1u) : lid - lpix * A.rpp;
     const uint32_t lrow = lpix / A.width;
     const uint32_t col = lpix - lrow * A.width;
     const uint32_t row = A.row0 + lrow;
@@ -441,9 +440,18 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
 // holds 256 / rpp whole pixels; one lane per (pixel, channel) adds that pixel's rpp samples in the reference's order -- sequential in i,
 // from +0: the fp32 sum is order-dependent -- reading them four at a time (a channel's row is contiguous in LDS); the four lanes of a pixel
 // (one DPP quad) hand their sums to the first, which writes `radiance` (the sums) and `pixel` (the tone-scaled RGBA8, truncating).
+#ifndef PT_RESOLVE_PRIO
+#define PT_RESOLVE_PRIO 1
+#endif
 PT_DEV void resolve_block(const FusedArgs& A, const float* rows, uint64_t first, uint64_t n_local) {
     const uint32_t rpp = A.rpp, ppb = 256u / rpp;
     const uint32_t pix0 = (uint32_t)(first / rpp), npix = (uint32_t)(n_local / rpp);
+#if PT_RESOLVE_PRIO
+    // The sums are chains of dependent additions (256 long at 256 rays per pixel, on four lanes) at the very end of a block whose other waves
+    // have left: until the chain ends the block's LDS and this wave's slot are held.  At the top priority the chain's instructions issue as they
+    // become ready instead of waiting their turn among the SIMD's other waves.
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (uint32_t q = threadIdx.x; q < 4u * ppb; q += 256u) {   // whole quads: 4 ppb is a multiple of 4, and so is every q - threadIdx.x
         const uint32_t j = q >> 2, c = q & 3u;
         const float* r = rows + c * 256u + j * rpp;
@@ -685,13 +693,7 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
             tri_words += S.nslots * 28u;   // records, vertex normals, material ids (stage_block), rounded up to whole float4s
             tris += S.nslots;
         }
-        // ... and the single-cell sphere sets (four words a sphere) for trace_spheres1; `first_zero`: the set's one cell starts at slot 0 (the host checked)
-        for (uint32_t i = 0; PT_SPHERE_LISTS && i < b.n_sets; ++i) {
-            GridArgs& S = b.sets[i];
-            if (S.n != 1u || S.kind != KIND_SPHERES || S.nslots == 0u || S.nslots > kLdsSphMax || !S.first_zero) continue;
-            S.lds_off = tri_base4 + tri_words;
-            tri_words += S.nslots * 4u;
-        }
+
     }
     // redo mode: one thread per 32-sample word of the mask, or (in-pass resolve: the mask is per block) one block per 32-block word
     const dim3 grid(redo_mask && a.resolve ? (unsigned)redo_words : (unsigned)((n + 255) / 256));

@@ -23,16 +23,20 @@ namespace pt {
 enum PtCounter { PC_WAVES = 0, PC_SEGMENTS, PC_SEG_LANES, PC_Q_CLOSEST, PC_Q_CLOSEST_LANES, PC_SWEEP_CLOSEST, PC_TRIPS_CLOSEST, PC_TRIP_LANES_CLOSEST,
                  PC_Q_SHADOW, PC_Q_SHADOW_LANES, PC_SWEEP_SHADOW, PC_TRIPS_SHADOW, PC_TRIP_LANES_SHADOW,
                  PC_SPH_Q_CLOSEST, PC_SPH_Q_CLOSEST_LANES, PC_SPH_TESTS_CLOSEST, PC_SPH_ROOTS_CLOSEST, PC_SPH_Q_SHADOW, PC_SPH_Q_SHADOW_LANES, PC_SPH_TESTS_SHADOW, PC_SPH_ROOTS_SHADOW,
-                 PC_BOX_TESTS, PC_BOX_LANES, PC_SHADE, PC_SHADE_LANES, PC_BOUNCE, PC_BOUNCE_LANES, PC_COUNT = 32 };
+                 PC_BOX_TESTS, PC_BOX_LANES, PC_SHADE, PC_SHADE_LANES, PC_BOUNCE, PC_BOUNCE_LANES,
+                 // the shared-test grid walk (pt_trace_coop.hpp): walks a wave enters, lanes that want one, outer phases, wave-level empty-cell steps and the lanes
+                 // taking them, pooled rounds, pairs; [closest, shadow] each
+                 PC_GRID_WALKS, PC_GRID_WANT_LANES = PC_GRID_WALKS + 2, PC_GRID_PHASES = PC_GRID_WALKS + 4, PC_GRID_A_STEPS = PC_GRID_WALKS + 6,
+                 PC_GRID_A_LANE_STEPS = PC_GRID_WALKS + 8, PC_GRID_ROUNDS = PC_GRID_WALKS + 10, PC_GRID_PAIRS = PC_GRID_WALKS + 12, PC_COUNT = 48 };
 #if PT_COUNT
 static __device__ unsigned long long pt_counters[PC_COUNT];
-__device__ __forceinline__ void pt_count(int i, bool lanes = false) {
+__device__ __forceinline__ void pt_count(int i, bool lanes = false, unsigned long long n = 1ull) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
     const unsigned me = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (me == (unsigned)__builtin_ctzll(m)) atomicAdd(&pt_counters[i], lanes ? (unsigned long long)__builtin_popcountll(m) : 1ull);
+    if (me == (unsigned)__builtin_ctzll(m)) atomicAdd(&pt_counters[i], lanes ? (unsigned long long)__builtin_popcountll(m) : n);
 }
 #else
-__device__ __forceinline__ void pt_count(int, bool = false) {}
+__device__ __forceinline__ void pt_count(int, bool = false, unsigned long long = 1ull) {}
 #endif
 
 struct Hit { uint32_t idx; float t, beta, gamma; };
@@ -355,7 +359,7 @@ PT_DEV uint32_t sign_word(float w) {
 // The block's dynamic LDS (launch_fused sizes it): [cooperative-walk exchange area (pt_trace_coop.hpp)] [staged cell-offset tables]
 // [staged single-cell triangle sets]: GridArgs::lds_off indexes it.  The walks read it through THIS symbol, so the compiler knows the
 // address space and emits ds_read (through a generic pointer selected at run time it emitted flat_load pairs).
-extern __shared__ uint32_t pt_lds_dyn[];
+extern __shared__ __attribute__((aligned(16))) uint32_t pt_lds_dyn[];   // read through float4 casts (ds_read_b128): every sub-area starts on a multiple of four words
 
 PT_DEV Box set_box_of(const GridArgs& S) {
     Box b;
@@ -536,83 +540,6 @@ PT_DEV Hit trace_cell1(const Ray& ray, const BoxHit& bh, const GridArgs& S) {
             done = done || better;
             if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every lane of the wave is blocked
         }
-    }
-    if (ANY && FLAG_ONLY && done) ch.idx = 0u;
-    return ch;
-}
-
-// A single-cell SPHERE set of the optimistic kernel through per-lane candidates (the spheres staged in the block's LDS: S.lds_off).
-// The wave-uniform loop of trace_cell1 runs the set's box test and then every sphere's whole test -- discriminant, square root, both roots,
-// the window -- for the wave, whatever share of its lanes can hit (cornell.xml: two spheres, a third of the lanes inside their box, and the
-// set was a quarter of the kernel).  Here the order is the reference's own early return first (code.cl:206-209, dis < 0), for every sphere
-// of the set in one wave-uniform sweep: omc, b, c and dis = mad(-4c, a, b b) with the reference's operations (14 instructions), the sign
-// of dis shifted into a per-lane word.  dis is -0 for no input (b b is +0 or positive, and (-0) + (+0) = +0), so "sign bit clear" is
-// exactly !(dis < 0) except for a NaN, whose test the reference's own comparisons reject wherever its sign bit says.  Only when some lane
-// of the wave holds a candidate does the set's BOX run at all -- interAABB (code.cl:335-389) gives nothing but the verdict and the window
-// [cmin, cmax] the roots are compared with, and a lane without a candidate has no root -- and then every lane walks ITS OWN candidates in
-// list order: the record from LDS, the same discriminant again (same operations, same bits), the root stage.  Ties on t go to the lower
-// index as in the reference's loop (strict <); a shadow lane stops at its first blocker.
-constexpr uint32_t kLdsSphMax = 64;   // spheres per staged set (4 words each)
-template <bool ANY, bool FLAG_ONLY>
-PT_DEV Hit trace_spheres1(const Ray& ray, const RayRcp& rr, const GridArgs& S) {
-    Hit ch;
-    ch.idx = UINT32_MAX;
-    ch.t = ray.maxt;
-    ch.beta = 0.0f;
-    ch.gamma = 0.0f;
-    const uint32_t end = S.nslots;   // (the set starts at slot 0: launch_fused only stages sets whose table says so)
-    const float a = dot3(ray.d, ray.d);
-    bool boxed = false, done = false;
-    float cmin = 0.0f, cmax = 0.0f, inv2a = 0.0f;
-    const pt_v4f PT_CONST_AS* p = (const pt_v4f PT_CONST_AS*)S.prims;
-    pt_count(ANY ? PC_SPH_Q_SHADOW : PC_SPH_Q_CLOSEST); pt_count(ANY ? PC_SPH_Q_SHADOW_LANES : PC_SPH_Q_CLOSEST_LANES, true);
-    for (uint32_t c0 = 0u; c0 < end; c0 += 32u) {
-        const uint32_t cnt = end - c0 < 32u ? end - c0 : 32u;
-        uint32_t neg = 0u;
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const float4 sph = ldc4((const void*)p, c0 + i);
-            pt_count(ANY ? PC_SPH_TESTS_SHADOW : PC_SPH_TESTS_CLOSEST);
-            const f3 omc = sub3(ray.o, ld3(sph));
-            const float b = 2.0f * dot3(omc, ray.d);
-            const float c = dot3(omc, omc) - sph.w;
-            const float dis = cl_mad(-4.0f * c, a, b * b);
-            neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(dis), 31);   // (neg << 1) | sign
-        }
-        uint32_t cand = ~neg << (32u - cnt);   // sphere c0 + k at bit 31 - k
-        if (ANY && done) cand = 0u;
-        if (__builtin_amdgcn_ballot_w64(cand != 0u) == 0ull) continue;   // the whole wave misses every sphere of the chunk
-        if (!boxed) {   // wave-uniform: the first chunk with a candidate
-            boxed = true;
-            const BoxHit bh = inter_aabb_t<true, false>(ray, rr, set_box_of(S));
-            cmin = bh.tmin;
-            cmax = bh.v ? cell1_exit(ray, bh, S) : -1.0f;   // a ray that misses the box: an empty window (cmin >= 0)
-            inv2a = rcp_refined(2.0f * a);
-        }
-        while (cand != 0u) {
-            pt_count(ANY ? PC_SPH_ROOTS_SHADOW : PC_SPH_ROOTS_CLOSEST);
-            const uint32_t k = (uint32_t)__builtin_clz(cand);
-            cand &= ~(0x80000000u >> k);
-            const uint32_t i = c0 + k;
-            const float4 sph = *(const float4*)&pt_lds_dyn[S.lds_off + 4u * i];
-            const f3 omc = sub3(ray.o, ld3(sph));
-            const float b = 2.0f * dot3(omc, ray.d);
-            const float c = dot3(omc, omc) - sph.w;
-            const float dis = cl_mad(-4.0f * c, a, b * b);
-            const float sq = cl_sqrt(dis);
-            const float t0 = (-b - sq) * inv2a, t1 = (-b + sq) * inv2a;   // ordered: t0 <= t1 (sph_test, ORDERED)
-            const int in0 = (t0 >= cmin) & (t0 <= cmax), in1 = (t1 >= cmin) & (t1 <= cmax);
-            const float ti = in0 ? t0 : t1;
-            const bool hit = (in0 | in1) != 0;
-            if (ANY && FLAG_ONLY) {
-                if (hit && ti < ray.maxt) { done = true; cand = 0u; }
-                continue;
-            }
-            const bool better = (int)hit & (int)(ti < ch.t);
-            ch.t = better ? ti : ch.t;
-            ch.idx = better ? i : ch.idx;
-            if (ANY && better) { done = true; cand = 0u; }
-        }
-        if (ANY && __builtin_amdgcn_ballot_w64(!done) == 0ull) break;
     }
     if (ANY && FLAG_ONLY && done) ch.idx = 0u;
     return ch;

@@ -97,6 +97,9 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
     ch.beta = 0.0f;
     ch.gamma = 0.0f;
     if (__builtin_amdgcn_ballot_w64(want) == 0ull) return ch;   // wave-uniform
+    constexpr int PCK = MODE == COOP_CLOSEST ? 0 : 1;
+    pt_count(PC_GRID_WALKS + PCK);
+    if (PT_COUNT && want) pt_count(PC_GRID_WANT_LANES + PCK, true);
     const float4* __restrict__ prims = (const float4*)S.prims;
     const uint32_t* __restrict__ off = (const uint32_t*)S.off;
     uint32_t tid = threadIdx.x;
@@ -158,7 +161,9 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
 
     for (;;) {
         // ---- phase A: through empty cells (code.cl:1028-1066's step, unchanged)
+        pt_count(PC_GRID_PHASES + PCK);
         while (alive && i == end) {
+            pt_count(PC_GRID_A_STEPS + PCK); pt_count(PC_GRID_A_LANE_STEPS + PCK, true);
             const float t = cmax;
             bool out;
 #if PT_COOP_RUNNING_CELL
@@ -211,7 +216,9 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
         const uint32_t cnt = alive ? end - i : 0u;
         const uint32_t incl = wave_scan_add(cnt), excl = incl - cnt;
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        pt_count(PC_GRID_PAIRS + PCK, false, total);
         for (uint32_t base = 0u; base < total; base += 64u) {
+            pt_count(PC_GRID_ROUNDS + PCK);
             // who owns pair base + lane: owners mark the first pair of theirs inside this window, a prefix maximum spreads the mark
             CW_MINE(CW_OWN) = 0u;
             if (cnt != 0u && excl < base + 64u && incl > base) CW_OF(CW_OWN, (excl > base ? excl : base) - base) = lane + 1u;

@@ -46,7 +46,7 @@ if (cmd === "pack") {
   const res = renderer.renderFile(file, w, h, rpp, passes, opt);
   writeFrame(out, res.pixel, w, h);
   fs.writeFileSync(out + ".radiance.f32", Buffer.from(res.radiance.buffer, res.radiance.byteOffset, res.radiance.byteLength));
-  process.stderr.write(`rendered ${file} ${w}x${h} rpp ${rpp}, ${passes} pass(es), ${opt.granular ? (opt.fusion ? "kernel-by-kernel, passes fused by the runtime" : "kernel-by-kernel") : "fused"}: ${res.ms.toFixed(2)} ms on ${res.device}\n`);
+  process.stderr.write(`rendered ${file} ${w}x${h} rpp ${rpp}, ${passes} pass(es), ${opt.granular ? (opt.fusion ? "kernel-by-kernel, passes fused by the runtime" : "kernel-by-kernel") : "fused"}: ${res.ms.toFixed(2)} ms on ${res.device}; passes the runtime fused from enqueues: ${res.fusedPasses}\n`);
 } else if (cmd === "pack-frame" || cmd === "frame") {
   if (rest.length < 4) usage();
   const frame = require("./frame.js");

@@ -101,9 +101,8 @@ class GranularRenderer {
     this.useGraph = !!opt.graph;
     this.ctx = opt.ctx || webcl.createContext(this.device);           // createCLBasicResources (code.js:576-608)
     // ours: with `fusion` the runtime runs each pass of this stream as one fused launch (webcl.createContext's default); without it this
-    // renderer is the launch-by-launch path on purpose
-    if (this.ownCtx && this.ctx.setFusion) this.ctx.setFusion(opt.fusion ? 2 : 0);
-    else if (opt.fusion && this.ctx.setFusion) this.ctx.setFusion(2);
+    // renderer is the launch-by-launch path on purpose -- whoever made the context (renderFile's --device-grid hands one in)
+    if (this.ctx.setFusion) this.ctx.setFusion(opt.fusion ? 2 : 0);
     this.q = this.ctx.createCommandQueue();
     this.program = this.ctx.createProgram(MANIFEST);
     this.program.build();
@@ -372,7 +371,7 @@ function renderFile(file, width, height, rpp, passes, opt) {
   for (let i = 0; i < passes; i++) R.executeRender(opt.bounces);
   const ms = R.q.timerStopMs();
   const res = { pixel: R.readPixels(), radiance: opt.granular ? radianceSums(R.readAcu(), rpp) : R.readRadiance(), ms: ms,
-                device: R.device.getInfo(webcl.DEVICE_NAME) };
+                device: R.device.getInfo(webcl.DEVICE_NAME), fusedPasses: R.ctx.fusedPasses ? R.ctx.fusedPasses() : 0 };
   R.release();
   if (ownCtx) ownCtx.release();
   return res;

@@ -61,6 +61,7 @@ SYMBOLS = {
     "mirt_device_count": (C.c_int, []),
     "mirt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "mirt_version": (C.c_char_p, []),
+    "mirt_abi_version": (C.c_int, []),
     "mirt_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mirt_ctx_destroy": (C.c_int, [C.c_void_p]),
     "mirt_last_error": (C.c_char_p, [C.c_void_p]),
@@ -115,6 +116,8 @@ SYMBOLS = {
     "mirt_group_finish": (C.c_int, [C.c_void_p]),
     "mirt_tile_rows": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mirt_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "mirt_group_peer_access": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mirt_gather_route": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 
@@ -503,6 +506,15 @@ class DeviceGroup:
         rc = lib().mirt_gather(self.h, hs, bs, n, out.h, root, transport)
         if rc != 0:
             raise MirtError(rc, lib().mirt_last_error(self.contexts[0].h).decode())
+
+    ROUTES = {0: "none", 1: "rccl", 2: "peer", 3: "staged", 4: "local"}
+
+    def routes(self):
+        """how the last gather moved each tile (mirt_gather_route)"""
+        return [self.ROUTES.get(lib().mirt_gather_route(self.h, i), "?") for i in range(len(self.contexts))]
+
+    def peer_access(self, i, j):
+        return lib().mirt_group_peer_access(self.h, i, j)
 
     def finish(self):
         rc = lib().mirt_group_finish(self.h)

@@ -263,9 +263,18 @@ class FramePacked:
             self.n_slabs, self.slab_size = int(d["n_slabs"]), np.asarray(d["slab_size"], np.uint32)
 
 
-def render_frame(ctx, p):
+def render_frame(ctx, p, timing=None):
     """compute() of A01 (code.js:166-269) / computeTri() of A04 (code.js:553-577) and A07 (code.js:603-628) over the C ABI:
-    same kernels, argument indices and NDRange.  Returns (pixels [H*W,4] uint8, rays bytes or None)."""
+    same kernels, argument indices and NDRange.  Returns (pixels [H*W,4] uint8, rays bytes or None).
+    timing: a dict that receives "trace_ms", the HIP-event time of the frame's trace kernel alone (raytrace / meshTrace / molTrace)."""
+    def timed(k, gws, l):
+        if timing is None:
+            return k.enqueue(gws, l)
+        ctx.finish()
+        ctx.timer_start()
+        k.enqueue(gws, l)
+        timing["trace_ms"] = ctx.timer_stop_ms()
+
     pre = {1: "A01:", 4: "A04:", 7: "A07:"}[p.assign]
     w, h = p.width, p.height
     l = get_local_ws(2, 64)
@@ -275,7 +284,7 @@ def render_frame(ctx, p):
     try:
         if p.assign == 1:
             k = ctx.kernel(pre + "raytrace").set_args(pixels, p.cam)
-            k.enqueue(gws, l)
+            timed(k, gws, l)
             k.release()
             return pixels.read(np.uint8).reshape(-1, 4), None
         k = ctx.kernel(pre + "sizeofRay")
@@ -293,7 +302,7 @@ def render_frame(ctx, p):
             mt = ctx.kernel(pre + "molTrace").set_args(pixels, p.cam, rays, _u32(p.s_size), up(p.atoms), up(p.mindex), up(p.mcolor), p.bounds,
                                                        _u32(p.n_slabs), up(p.slab_size))
             it.enqueue(gws, l)
-            mt.enqueue(gws, l)
+            timed(mt, gws, l)
             ctx.finish()
             it.release(); mt.release()
             return pixels.read(np.uint8).reshape(-1, 4), rays.read(np.uint8)
@@ -301,10 +310,36 @@ def render_frame(ctx, p):
         if p.assign == 7:
             mt.set_arg(8, p.bounds).set_arg(9, _u32(p.n_slabs)).set_arg(10, up(p.slab_size))
         it.enqueue(gws, l)
-        mt.enqueue(gws, l)
+        timed(mt, gws, l)
         ctx.finish()
         it.release(); mt.release()
         return pixels.read(np.uint8).reshape(-1, 4), rays.read(np.uint8)
     finally:
         for b in keep:
             b.release()
+
+
+def frame_resized(d, w, h):
+    """The same frame job at another size: Camera.set (A07 code.js:55-71) makes width = height * cols / rows; cols, rows ride in .sE / .sF."""
+    d = dict(d, width=w, height=h)
+    cam = list(d["cam"])
+    cam[12] = float(np.float32(cam[13] * (w / h)))
+    cam[14], cam[15] = float(w), float(h)
+    d["cam"] = cam
+    return d
+
+
+def frame_regrid(ctx, a07_job, a04_job, n):
+    """The Assign07 job of a mesh at another n_slabs, binned ON THE DEVICE (mirt_grid_build + gathers = splitMeshData, A07 code.js:631-767):
+    the mesh's triangles in input order come from its Assign04 job (one slot per triangle), the bounds from the Assign07 job."""
+    tri = np.asarray(a04_job["pos"], np.float32).reshape(-1, 3, 4)[:, :, :3].reshape(-1, 9).astype(np.float64)
+    nor = np.asarray(a04_job["normal"], np.float32).reshape(-1, 3, 4)[:, :, :3].reshape(-1, 9).astype(np.float64)
+    b = np.asarray(a07_job["bounds"], np.float64)
+    off, order, total = ctx.grid_build(1, tri, [b[0], b[1], b[2], b[4], b[5], b[6]], n)
+    pos, nrm = ctx.grid_gather_triangles(order, total, tri, nor, pad_w=0.0)
+    mi = ctx.grid_gather_u32(order, total, np.asarray(a04_job["mindex"], np.uint32))
+    out = dict(a07_job, n_slabs=n, slab_size=off.read(np.uint32).tolist(), pos=pos.read(np.float32, total * 12).tolist(),
+               normal=nrm.read(np.float32, total * 12).tolist(), mindex=mi.read(np.uint32, total).tolist())
+    for buf in (off, order, pos, nrm, mi):
+        buf.release()
+    return out

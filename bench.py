@@ -40,6 +40,10 @@ FLOPS_PER_SAMPLE = {"cornell": {5: 6612.3, 8: 9788.3}, "cornell_teapot3": {5: 10
 SCENE_FIXTURE = {"cornell_teapot3": "cornell_teapot3_32x24_r4", "cornell_official": "cornell_official_64x48_r1", "basic": "basic_32x24_r4",
                  "triangles": "triangles_32x24_r4", "twoLights": "twoLights_32x24_r4", "threeLights": "threeLights_32x24_r1",
                  "own_gems": "own_gems_48x36_r4", "own_studio": "own_studio_48x36_r4", "own_flat": "own_flat_32x24_r4"}
+# Configs 2 and 3 (SURVEY 8d "flops = W*H*sum(tests by exit)"): algorithmic fp32 operations per pixel of the reference's own nested loops, measured at the
+# configs' full sizes by the counting oracle (make -C oracle count && python oracle/count_flops_frames.py)
+FRAME_FLOPS_PER_PIXEL = {"a04_parliament_1024": 260428.3, "a04_teapot_1024": 28400.0,
+                         "a07_parliament_1080p_n2": 8085.5, "a07_parliament_1080p_n16": 211.4, "a07_parliament_1080p_n32": 118.9}
 BYTES_PER_SAMPLE_SEED = 8.0         # seed 4 in + 4 out: all a sample moves when the pass resolves its pixels itself
 BYTES_PER_SAMPLE_ACU = 16.0         # + the per-ray accumulator written (--keep-acu, or a ray count that does not divide 256)
 BYTES_PER_PIXEL_RESOLVE = 4.0 + 16.0   # RGBA8 + the fp32 radiance sums
@@ -151,6 +155,83 @@ def reference_gpu_baseline(packed_json, log, bounces):
             "sample": f"the same scene at {sc.width}x{sc.height} rpp16 1 pass {bounces} bounces ({n} samples, {dt * 1e3:.1f} ms per pass)"}
 
 
+def grid_scene_record(ctx, log, render, scene, cpu):
+    """The grid kernel beside the headline: cornell_teapot3.xml (992-triangle teapot in 10^3 cells + a 20-triangle box in 5^3, two lights: the scene class
+    seven of the reference's ten A10 scenes belong to) at 1920x1080 x 16 rays per pixel, five bounces (the reference's depth) and eight."""
+    name = "cornell_teapot3"
+    fxs = np.load(os.path.join(ROOT, "tests", "golden", SCENE_FIXTURE[name] + ".npz"))
+    sc = scene.PackedScene(bytes(fxs["scene_json"]).decode()).resized(1920, 1080, 16)
+    fr = render.FusedRenderer(ctx, sc, want_radiance=True, keep_acu=False)
+    out = {"workload": f"A10 {name}.xml path trace 1920x1080, 16 spp, 1 pass; fused mirt_render_first_pass (k_fusedPass<true,1,*>: shared-test grid walk)",
+           "samples": fr.nrays}
+    for bounces in (5, 8):
+        ms = []
+        for i in range(4):
+            ctx.seed_fill(fr.seeds, fr.first_ray, fr.nrays, 0)
+            fr.passes = 1
+            fr.execute_render(bounces=bounces, fresh=True)
+            if i:
+                ms.append(ctx.pass_timing()[0])
+        t = float(np.mean(ms))
+        fl = FLOPS_PER_SAMPLE[name][bounces]
+        out[f"depth{bounces}"] = {"launch_ms": round(t, 3), "Msamples_per_s_kernel": round(fr.nrays / t / 1e3, 1), "flops_per_sample": fl,
+                                 "achieved_TFLOPs": round(fl * fr.nrays / (t * 1e-3) / 1e12, 2), "frac": round(fl * fr.nrays / (t * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4)}
+    fr.release()
+    if cpu:
+        c = cpu_baseline(json.dumps(sc.d), log, 5, 16)
+        out["cpu_baseline"] = c
+    return out
+
+
+def frames_record(ctx, log, render, cpu):
+    """BASELINE configs 2 and 3 at full size: Assign04 brute force (house_of_parliament, 9 144 triangles, and teapot, 992) at 1024 x 1024; Assign07
+    uniform-grid traversal of house_of_parliament at 1920 x 1080, n_slabs 2 (the page's default) / 16 / 32 (2 and 32 binned on the device, mirt_grid_build).
+    Kernel time = HIP events around the trace kernel alone; flops = the reference's own nested loops' operations (FRAME_FLOPS_PER_PIXEL)."""
+    def job(name):
+        fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        return json.loads(bytes(fx["frame_json"]).decode())
+    a04, a07, tea = job("frame_a04_parliament_96x64"), job("frame_a07_parliament_n16_160x120"), job("frame_a04_teapot_160x120")
+    jobs = [("a04_parliament_1024", render.frame_resized(a04, 1024, 1024)), ("a04_teapot_1024", render.frame_resized(tea, 1024, 1024))]
+    for n in (2, 16, 32):
+        jobs.append((f"a07_parliament_1080p_n{n}", render.frame_resized(a07 if n == 16 else render.frame_regrid(ctx, a07, a04, n), 1920, 1080)))
+    out = {}
+    for tag, d in jobs:
+        fp = render.FramePacked(d)
+        render.render_frame(ctx, fp)   # warm-up: prepares the triangles, validates the cell table
+        ms = []
+        for _ in range(5):
+            t = {}
+            render.render_frame(ctx, fp, timing=t)
+            ms.append(t["trace_ms"])
+        k_ms = float(np.median(ms))
+        npx = d["width"] * d["height"]
+        fl = FRAME_FLOPS_PER_PIXEL[tag] * npx
+        rec = {"kernel": "pt::k_a04_meshTrace" if d["assign"] == 4 else "pt::k_a07_meshTrace", "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(min(ms), 4),
+               "Mrays_per_s": round(npx / k_ms / 1e3, 1), "flops_per_pixel": FRAME_FLOPS_PER_PIXEL[tag],
+               "achieved_TFLOPs": round(fl / (k_ms * 1e-3) / 1e12, 2), "frac": round(fl / (k_ms * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4)}
+        if d["assign"] == 4:
+            rec["pairs_per_s_T"] = round(npx * d["t_size"] / (k_ms * 1e-3) / 1e12, 2)
+        out[tag] = rec
+    out["note"] = ("flops are the REFERENCE's work (its nested loops, every test to its own exit); the kernels skip whole groups of 16 triangles whose bounding sphere "
+                   "every ray of the wave misses, bit-identical pixels -- so `frac` prices the reference's operations against the kernel's time and may exceed 1 "
+                   "(a04_parliament, a07 n = 2): it is a speed-up over doing the reference's arithmetic at peak, not a utilisation")
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import frame_pass as F
+        base = {}
+        for tag, d, (w, h) in (("a04_parliament", a04, (256, 256)), ("a07_parliament_n16", a07, (960, 540))):
+            fr = F.Frame(render.frame_resized(d, w, h))
+            t0 = time.perf_counter()
+            F.run_frame("oracle", fr)
+            dt = time.perf_counter() - t0
+            base[tag] = {"value": round(w * h / dt / 1e6, 3), "unit": "Mrays/s", "kind": "port", "sample": f"{w}x{h}, {dt:.2f} s wall"}
+        import a10_pass as A
+        k = A.load_oracle()
+        k.lib.oracle_num_threads.restype = int
+        out["cpu_baseline"] = dict(base, cores=k.lib.oracle_num_threads())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +245,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--no-depth5", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-records beside the headline: grid_scene (cornell_teapot3) and frames (configs 2 / 3)")
     ap.add_argument("--keep-acu", action="store_true", help="keep the 16-byte per-ray accumulator (what a progressive second pass needs); default: the one-pass "
                     "frame without it -- the pass resolves its pixels itself, 8 B per sample + 20 B per pixel (SURVEY 8d)")
     ap.add_argument("--pmc-summary", default=None, help="pmc_summary.json of a rocprofv3 run of this command (profiles/run_profile.sh); default: the "
@@ -233,6 +315,8 @@ def main():
     fr.pixel = ctx.wrap(tile.data_ptr(), max_rows * sc.width * 4)
     frame = torch.empty(world * tile.numel(), dtype=torch.uint8, device="cuda") if use_dist else None
 
+    gather_ev = []   # (start, stop) torch events around each step's all_gather, on the stream the kernels run on
+
     def step():
         # a step re-renders the same frame: restore the seeds it started from; the accumulator is initialised by the pass itself
         # (mirt_render_first_pass = preRender's initAcu folded into the first pass, A10 code.js:1078-1099)
@@ -240,7 +324,11 @@ def main():
         fr.passes = 1
         fr.execute_render(bounces=args.bounces, fresh=True)
         if use_dist:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             tiling.gather_tiles(tile, frame)
+            e1.record()
+            gather_ev.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize()
@@ -251,6 +339,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    gather_ev.clear()
     kern_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -263,6 +352,17 @@ def main():
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
 
+    # N > 1: every rank's own kernel time and its gather's own event time (the all_gather includes waiting for the slowest rank), so that a
+    # first run on N real GPUs is diagnosable from its one line: load imbalance shows in launch_ms, transport trouble in gather_ms
+    per_rank = None
+    if use_dist:
+        mine = torch.tensor([float(np.mean([k[0] for k in kern_ms])), float(np.mean([a.elapsed_time(b) for a, b in gather_ev])) if gather_ev else 0.0,
+                             float(nrows)], dtype=torch.float64, device="cuda")
+        allr = torch.empty(world * 3, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(allr, mine)
+        a = allr.view(world, 3).cpu().numpy()
+        per_rank = {"launch_ms": [round(float(x), 3) for x in a[:, 0]], "gather_ms": [round(float(x), 3) for x in a[:, 1]], "rows": [int(x) for x in a[:, 2]],
+                    "gather": "torch.distributed all_gather_into_tensor (RCCL) of padded RGBA8 tiles, %d bytes per rank" % tile.numel()}
     samples_per_step = sc.width * sc.height * sc.rpp
     value = samples_per_step * args.steps / dt / 1e6
     fused_ms = float(np.mean([k[0] for k in kern_ms]))
@@ -317,6 +417,8 @@ def main():
                          "bytes_per_sample": round(bytes_per_sample, 3), "resolve": "in the pass (no per-ray accumulator)" if no_acu else "separate copyToPixel over acu"},
         "build": {"csrc_sha256": csrc_sha256()[:16]},
     }
+    if per_rank:
+        out["per_rank"] = per_rank
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(packed, log, args.bounces, sc.rpp)
         try:
@@ -337,6 +439,14 @@ def main():
         out["depth5"] = {"launch_ms": round(float(np.mean(t5)), 3), "Msamples_per_s_kernel": round(fr.nrays / np.mean(t5) / 1e3, 1),
                          "flops_per_sample": fps_table[5], "frac": round(fps_table[5] * fr.nrays / (np.mean(t5) * 1e-3) / 1e12 / PEAK_VALU_TFLOPS, 4)}
     fr.release()
+    if rank == 0 and world == 1 and args.scene == "cornell" and not args.no_extras:
+        # beside the headline: the grid kernel and BASELINE configs 2 / 3, each with its own roofline fraction and a bounded CPU baseline
+        try:
+            out["grid_scene"] = grid_scene_record(ctx, log, render, scene, not args.no_cpu)
+            out["frames"] = frames_record(ctx, log, render, not args.no_cpu)
+        except Exception as e:   # sub-records never cost the headline line
+            log(f"extras skipped: {type(e).__name__}: {e}")
+            out["extras_error"] = f"{type(e).__name__}: {e}"
     ctx.destroy()
     if use_dist:
         dist.destroy_process_group()

@@ -64,6 +64,11 @@ typedef enum mirt_status {
 MIRT_API int mirt_device_count(void);
 MIRT_API int mirt_device_name(int device, char* out, size_t cap);
 MIRT_API const char* mirt_version(void);
+/* Bumped whenever an existing entry point changes its parameters or the meaning of a value (a caller built against an older header would link and
+ * pass shifted arguments).  4: mirt_gather takes n_tiles and a transport enum (round 3); mirt_pass_desc.acu may be NULL (round 4).  Check
+ * mirt_abi_version() == MIRT_ABI_VERSION before anything else. */
+#define MIRT_ABI_VERSION 4
+MIRT_API int mirt_abi_version(void);
 
 /* ---- context + command queue: webcl.createContext(device) + ctx.createCommandQueue()
  *      (A10 code.js:582, 592); release() of both (code.js:1539-1552) ------------------- */
@@ -324,6 +329,18 @@ MIRT_API void mirt_tile_rows(uint32_t height, uint32_t n_tiles, uint32_t index, 
  * (n_tiles must equal mirt_group_size); `out` is a buffer of context `root`.  Ordered after the work queued on each context; complete after mirt_finish(root ctx). */
 enum { MIRT_GATHER_AUTO = 0, MIRT_GATHER_RCCL = 1, MIRT_GATHER_COPY = 2 };
 MIRT_API int mirt_gather(mirt_group* g, mirt_buf* const* tiles, const size_t* tile_bytes, int n_tiles, mirt_buf* out, int root, int transport);
+/* What a group can do and what the last gather did.  mirt_group_create asks hipDeviceCanAccessPeer for every pair of distinct devices and enables peer
+ * access both ways; mirt_group_peer_access(g, i, j) = 1 when context i's device reads context j's device's memory directly (always 1 for i == j and for
+ * contexts that share a device), 0 when the runtime refused -- then a copy between them is staged through host memory by the HIP runtime.
+ * mirt_gather_route(g, tile): how the LAST mirt_gather moved that tile -- MIRT_GATHER_AUTO may pick copies without saying so (librccl absent, a
+ * rehearsal group), and a staged copy is an order of magnitude slower than a peer one: a first run on N real GPUs is diagnosable from these. */
+enum { MIRT_ROUTE_NONE = 0,   /* no gather yet, or an empty tile                                       */
+       MIRT_ROUTE_RCCL = 1,   /* ncclSend / ncclRecv                                                    */
+       MIRT_ROUTE_PEER = 2,   /* hipMemcpyPeerAsync between devices with peer access enabled (xGMI P2P) */
+       MIRT_ROUTE_STAGED = 3, /* hipMemcpyPeerAsync WITHOUT peer access: bounced through host memory    */
+       MIRT_ROUTE_LOCAL = 4 };/* the tile already lives on the root's device: a device-local copy      */
+MIRT_API int mirt_group_peer_access(const mirt_group* g, int i, int j);
+MIRT_API int mirt_gather_route(const mirt_group* g, int tile);
 
 /* ---- measurement: HIP events on the context's stream ---------------------------------- */
 MIRT_API int mirt_timer_start(mirt_ctx* ctx);

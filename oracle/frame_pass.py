@@ -20,6 +20,10 @@ def _lib(kind, assign):
         lib = C.CDLL(os.path.join(HERE, "_ref", f"libref_a{assign:02d}.so"))
         A.set_hw_tables(lib, "ref_")
         return lib, f"ref_a{assign:02d}_"
+    if kind == "count":   # the single-threaded build with the fp32-operation counters (make -C oracle count; count_flops.py)
+        lib = C.CDLL(os.path.join(HERE, "liboracle_count.so"))
+        A.set_hw_tables(lib, "oracle_")
+        return lib, f"oracle_a{assign:02d}_"
     lib = C.CDLL(os.path.join(HERE, "liboracle.so"))
     A.set_hw_tables(lib, "oracle_")
     lib.oracle_set_threads.argtypes = [C.c_int]

@@ -32,8 +32,19 @@ static unsigned long long g_flops;
 #define FL(n) (g_flops += (unsigned long long)(n))
 unsigned long long oracle_flops_get(void) { return g_flops; }
 void oracle_flops_reset(void) { g_flops = 0; }
+/* grid-walk statistics of the triangle walks over grids with n > 1 (profiles/walk_stats.py: how much of the walk's work is a triangle tested
+ * again in a later cell).  [0] walks, [1] cells visited, [2] cells with a list, [3] tests, [4] tests of a triangle this ray already tested in
+ * an earlier cell of the walk, [5] ... whose earlier test was rejected for a reason no cell changes (facing, barycentrics), [6] ... rejected
+ * by the cell's window alone, [7] walks that end with a hit, [8] tests the reference makes in cells that start beyond the ray's end (the
+ * product's walks stop there). */
+static unsigned long long g_walk[16];
+static int g_last_reject;   /* of the last inter_triangle: 0 accepted, 1 facing, 2 barycentrics, 3 window */
+#define REJ(k) (g_last_reject = (k))
+void oracle_walk_stats_get(unsigned long long* out) { for (int i = 0; i < 16; ++i) out[i] = g_walk[i]; }
+void oracle_walk_stats_reset(void) { for (int i = 0; i < 16; ++i) g_walk[i] = 0; }
 #else
 #define FL(n) ((void)0)
+#define REJ(k) ((void)0)
 unsigned long long oracle_flops_get(void) { return 0; }
 void oracle_flops_reset(void) {}
 #endif
@@ -249,20 +260,21 @@ static int inter_triangle(const ray_t* r, const float* tp /* 3 x float4 */, floa
     v3 e1 = sub(p1, p0);
     v3 e2 = sub(p2, p0);
     float div = dot3(cross3(e2, e1), r->d);
-    if (div <= 0) return 0;
+    if (div <= 0) { REJ(1); return 0; }
     FL(2);
     float idiv = 1.0f / div;
     v3 s = sub(r->o, p0);
     float beta = dot3(cross3(s, r->d), e2) * idiv;
-    if (beta < 0.0f || beta > 1.0f) return 0;
+    if (beta < 0.0f || beta > 1.0f) { REJ(2); return 0; }
     FL(1);
     float gamma = dot3(cross3(s, e1), r->d) * idiv;
     FL(1);
     float gb = gamma + beta;
-    if (gamma < 0.0f || gb < 0.0f || gb > 1.0f) return 0;
+    if (gamma < 0.0f || gb < 0.0f || gb > 1.0f) { REJ(2); return 0; }
     FL(1);
     float t = dot3(cross3(s, e2), e1) * -idiv;
-    if (t >= r->mint && t <= r->maxt) { *t_out = t; *beta_out = beta; *gamma_out = gamma; return 1; }
+    if (t >= r->mint && t <= r->maxt) { *t_out = t; *beta_out = beta; *gamma_out = gamma; REJ(0); return 1; }
+    REJ(3);
     return 0;
 }
 
@@ -309,20 +321,50 @@ static champ_t grid_trace(ray_t ray /* by value: mint/maxt are clobbered per cel
     ch.beta = ch.gamma = 0.0f;
     float t = bh.tmin;
     const uint32_t zs = n * n, ys = n;
+#ifdef PTO_COUNT_FLOPS
+    const int stats = kind == PRIM_TRIANGLE && n > 1;
+    const float ray_end = ray.maxt;
+    struct { const float* rec; int rej; } seen[512];
+    int n_seen = 0;
+    if (stats) g_walk[0]++;
+#endif
     for (;;) {
         ray.mint = t;
         ray.maxt = cln_min(cln_min(ax.tnext, ay.tnext), az.tnext);
         uint32_t cell = (uint32_t)az.slab * zs + (uint32_t)ay.slab * ys + (uint32_t)ax.slab;
         uint32_t begin = cell_off[cell], end = cell_off[cell + 1];
+#ifdef PTO_COUNT_FLOPS
+        if (stats) { g_walk[1]++; if (end > begin) g_walk[2]++; }
+#endif
         for (uint32_t i = begin; i < end; ++i) {
             float ti, b = 0.0f, g = 0.0f;
             int hit = (kind == PRIM_SPHERE) ? inter_sphere(&ray, prims + 4u * (size_t)i, &ti)
                                             : inter_triangle(&ray, prims + 12u * (size_t)i, &ti, &b, &g);
+#ifdef PTO_COUNT_FLOPS
+            if (stats) {
+                if (t >= ray_end) g_walk[8]++;
+                else {
+                    g_walk[3]++;
+                    int k;
+                    for (k = 0; k < n_seen; ++k)
+                        if (memcmp(seen[k].rec, prims + 12u * (size_t)i, 48) == 0) break;
+                    if (k < n_seen) {
+                        g_walk[4]++;
+                        if (seen[k].rej == 1 || seen[k].rej == 2) g_walk[5]++;
+                        else if (seen[k].rej == 3) g_walk[6]++;
+                        seen[k].rej = g_last_reject;
+                    } else if (n_seen < 512) { seen[n_seen].rec = prims + 12u * (size_t)i; seen[n_seen].rej = g_last_reject; ++n_seen; }
+                }
+            }
+#endif
             if (hit && ti < ch.t) {
                 ch.t = ti; ch.idx = i; ch.beta = b; ch.gamma = g;
                 if (any_hit) break;
             }
         }
+#ifdef PTO_COUNT_FLOPS
+        if (stats && ch.idx < UINT_MAX) g_walk[7]++;
+#endif
         if (ch.idx < UINT_MAX) break;
         t = ray.maxt;
         if (t == ax.tnext) {

@@ -6,7 +6,7 @@
 set -uo pipefail
 for lib in ab/libmirt_*.so; do
   old=0; for o in ${AB_OLD:-}; do [ "$(basename $lib)" = "$o" ] && old=1; done
-  r=$(MIRT_INPASS_RESOLVE=$((1-old)) MIRT_LIB_PATH="$PWD/$lib" timeout -k 10 200 python3 bench.py --steps ${AB_STEPS:-5} --warmup 2 --no-cpu --no-depth5 2>/dev/null)
+  r=$(MIRT_INPASS_RESOLVE=$((1-old)) MIRT_LIB_PATH="$PWD/$lib" timeout -k 10 200 python3 bench.py --steps ${AB_STEPS:-5} --warmup 2 --no-cpu --no-depth5 --no-extras 2>/dev/null)
   echo "$(basename $lib) $(echo "$r" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print("launch_ms", d["roofline"]["launch_ms"], "ms_per_step", d["ms_per_step"], "value", d["value"])' 2>/dev/null || echo FAILED)"
 done
 if [ -n "${AB_SCENES:-}" ]; then for lib in ab/libmirt_*.so; do

@@ -5,7 +5,7 @@ set -uo pipefail
 OUT="${1:-gpurun_out/ab_resolve}"; mkdir -p "$OUT"
 run() {  # tag, env..., -- bench args
   local tag="$1"; shift
-  local r; r=$(env "$@" timeout -k 10 300 python3 bench.py --steps 5 --warmup 2 --no-cpu --no-depth5 ${BENCH_ARGS:-} 2>"$OUT/$tag.err") || { echo "$tag FAILED"; tail -3 "$OUT/$tag.err"; return 1; }
+  local r; r=$(env "$@" timeout -k 10 300 python3 bench.py --steps 5 --warmup 2 --no-cpu --no-depth5 --no-extras ${BENCH_ARGS:-} 2>"$OUT/$tag.err") || { echo "$tag FAILED"; tail -3 "$OUT/$tag.err"; return 1; }
   echo "$r" > "$OUT/$tag.json"
   echo "$tag $(echo "$r" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print("ms_per_step", d["ms_per_step"], "launch_ms", d["roofline"]["launch_ms"], "resolve_ms", d["roofline"]["resolve_ms"], "value", d["value"])')"
 }

@@ -19,7 +19,10 @@ import __graft_entry__ as graft  # noqa: E402
 NAMES = ["waves", "segments", "seg_lanes", "q_closest", "q_closest_lanes", "sweep_closest", "trips_closest", "trip_lanes_closest",
          "q_shadow", "q_shadow_lanes", "sweep_shadow", "trips_shadow", "trip_lanes_shadow",
          "sph_q_closest", "sph_q_closest_lanes", "sph_tests_closest", "sph_roots_closest", "sph_q_shadow", "sph_q_shadow_lanes", "sph_tests_shadow", "sph_roots_shadow",
-         "box_tests", "box_lanes", "shade", "shade_lanes", "bounce", "bounce_lanes"]
+         "box_tests", "box_lanes", "shade", "shade_lanes", "bounce", "bounce_lanes",
+         "grid_walks_closest", "grid_walks_shadow", "grid_want_lanes_closest", "grid_want_lanes_shadow", "grid_phases_closest", "grid_phases_shadow",
+         "grid_a_steps_closest", "grid_a_steps_shadow", "grid_a_lane_steps_closest", "grid_a_lane_steps_shadow", "grid_rounds_closest", "grid_rounds_shadow",
+         "grid_pairs_closest", "grid_pairs_shadow"]
 
 
 def main():
@@ -38,7 +41,7 @@ def main():
         raise SystemExit("this libmirt.so is not a counting build (-DPT_COUNT=1)")
     ctx = mirt.Context(0)
     fr = render.FusedRenderer(ctx, sc, keep_acu=False)
-    out = (C.c_ulonglong * 32)()
+    out = (C.c_ulonglong * 48)()
     lib.mirt_debug_counters(None, 1)
     fr.execute_render(bounces=bounces, fresh=True)
     ctx.finish()

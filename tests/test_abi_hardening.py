@@ -129,6 +129,7 @@ def test_device_group_renders_row_tiles_and_gathers(M, pkg, use_rccl):
     fr.execute_render()
     frame = ctx.buffer(sc.width * sc.height * 4)
     grp.gather([fr.pixel], [sc.width * sc.height * 4], frame, root=0, use_rccl=use_rccl)
+    assert grp.routes() == ["rccl" if use_rccl else "local"]   # what the gather did, as the group reports it (mirt_gather_route)
     grp.finish()
     assert np.array_equal(frame.read(np.uint8).reshape(-1, 4), fx["pixel"])
     # tile arithmetic: contiguous, sizes differ by at most one row, cover the image
@@ -172,8 +173,13 @@ def test_device_group_n_contexts_render_tiles_and_gather(M, pkg, n, monkeypatch)
     frame, rad = root.buffer(npix * 4), root.buffer(npix * 16)
     assert code(grp.gather, [f.pixel for f in frs], [f.npix * 4 for f in frs], frame, transport=M.DeviceGroup.GATHER_RCCL) == E_ARG   # one device per rank
     assert code(grp.gather, [f.pixel for f in frs][:-1], [f.npix * 4 for f in frs][:-1], frame) == E_ARG                               # one tile per context
+    assert grp.routes() == ["none"] * n                      # nothing gathered yet
+    assert all(grp.peer_access(i, j) == 1 for i in range(n) for j in range(n))   # contexts that share a device reach each other's memory
+    assert grp.peer_access(0, n) < 0 and grp.peer_access(-1, 0) < 0
     grp.gather([f.pixel for f in frs], [f.npix * 4 for f in frs], frame)
+    assert grp.routes() == ["local"] * n                     # AUTO on a rehearsal group: device-local copies, and the group says so
     grp.gather([f.radiance for f in frs], [f.npix * 16 for f in frs], rad, transport=M.DeviceGroup.GATHER_COPY)
+    assert grp.routes() == ["local"] * n
     grp.finish()
     assert np.array_equal(frame.read(np.uint8).reshape(-1, 4), fx["pixel"])
     assert np.array_equal(rad.read(np.float32).view(np.uint32).reshape(-1, 4), fx["radiance"].view(np.uint32).reshape(-1, 4))

@@ -26,6 +26,12 @@ def test_library_exports_every_declared_symbol(pkg):
     assert b"gfx950" in lib.mirt_version()
 
 
+def test_abi_version_matches_the_header(pkg):
+    from raytracing_amd.pyhost import mirt
+    text = open(os.path.join(ROOT, "include", "mirt.h")).read()
+    assert mirt.lib().mirt_abi_version() == int(re.search(r"#define MIRT_ABI_VERSION (\d+)", text).group(1))
+
+
 def test_no_cpu_fallback(pkg):
     from raytracing_amd.pyhost import mirt
     if mirt.device_count() > 0:

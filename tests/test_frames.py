@@ -263,3 +263,23 @@ def test_random_meshes_frames_match_oracle(ctx, pkg, seed, n):
     want, wrays = F.run_frame("oracle", F.Frame(d))
     assert np.array_equal(px, want)
     assert (px[:, :3].max(axis=1) > 0).mean() > 0.004
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 16, 32])
+def test_device_regrid_equals_the_host_binning(ctx, pkg, n):
+    """pyhost render.frame_regrid (bench.py's configs 2 / 3 record bins house_of_parliament at n = 2 and 32 with it: mirt_grid_build + gathers)
+    against the restatement of the reference host's splitMeshData -- and, at n = 16, against the reference host's own grid the fixture carries."""
+    from raytracing_amd.pyhost import render
+    _, g = fixture("frame_a07_parliament_n16_160x120")
+    _, flat = fixture("frame_a04_parliament_96x64")
+    got = render.frame_regrid(ctx, g, flat, n)
+    want = g if n == 16 else regrid(g, flat, n)
+    assert got["n_slabs"] == n and got["slab_size"] == [int(x) for x in want["slab_size"]]
+    for key in ("pos", "normal"):
+        assert np.array_equal(bits(np.asarray(got[key], np.float32)), bits(np.asarray(want[key], np.float32))), key
+    assert got["mindex"] == [int(x) for x in want["mindex"]]
+    t = {}
+    px, _ = render.render_frame(ctx, render.FramePacked(render.frame_resized(got, 320, 180)), timing=t)
+    px2, _ = render.render_frame(ctx, render.FramePacked(resized(want, 320, 180)))
+    assert np.array_equal(px, px2) and t["trace_ms"] > 0

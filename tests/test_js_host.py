@@ -17,10 +17,10 @@ pytestmark = pytest.mark.skipif(node is None, reason="node is not installed")
 REF_PAGE = "/root/reference/Assign10-Path_Tracing"
 
 
-def run_node(*args, **kw):
+def run_node(*args, stderr=False, **kw):
     r = subprocess.run([node] + list(args), capture_output=True, **kw)
     assert r.returncode == 0, r.stderr.decode()
-    return r.stdout
+    return r.stderr.decode() if stderr else r.stdout
 
 
 def same_packed(a, b, path=""):
@@ -144,11 +144,14 @@ def test_node_render_matches_compiled_reference(tmp_path, name, mode):
         args.append("--device-grid")
     if "fusion" in mode:   # the same enqueues, recognised by the runtime and run as one fused launch per pass (mirt_ctx_set_fusion)
         args.append("--fusion")
-    run_node(*args)
+    log = run_node(*args, stderr=True)
     pix = np.fromfile(out, np.uint8).reshape(-1, 4)
     rad = np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)
     assert np.array_equal(pix, fx["pixel"])
     assert np.array_equal(bits(rad), bits(fx["radiance"]))
+    # the kernel-by-kernel modes really launch kernel by kernel (whoever made the context), `--fusion` really fuses
+    fused = int(log.rsplit("fused from enqueues:", 1)[1].split()[0])
+    assert fused == (1 if mode == "granular+fusion" else 0), log
 
 
 def test_node_tile_arithmetic_matches_python():
