@@ -254,8 +254,11 @@ int check_grid(mirt_ctx* ctx, const char* what, mirt_buf* off, uint32_t n, const
         std::vector<uint32_t> h(cells + 1);
         HIPCHK(ctx, hipMemcpyAsync(h.data(), off->ptr, (cells + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint64_t i = 0; i < cells; ++i)
+        for (uint64_t i = 0; i < cells; ++i) {
             if (h[i] > h[i + 1]) return fail(ctx, MIRT_E_DATA, "%s: cell offsets decrease at cell %llu", what, (unsigned long long)i);
+            if (n > 1 && h[i + 1] - h[i] >= pt::kMaxCellSlots)
+                return fail(ctx, MIRT_E_RANGE, "%s: cell %llu holds %u slots (a cell of a grid holds at most %u)", what, (unsigned long long)i, h[i + 1] - h[i], pt::kMaxCellSlots - 1u);
+        }
         off->off_version = off->version;
         off->off_n = n;
         off->off_last = h[cells];

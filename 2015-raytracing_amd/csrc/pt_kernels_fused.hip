@@ -221,7 +221,7 @@ PT_DEV void closest_all(const FusedArgs& A, Ray& ray, Poi& poi, const PARK& park
         } else if (S.kind == KIND_TRIANGLES) {   // every lane of the wave enters: the tests of the walk are shared (pt_trace_coop.hpp)
             BoxHit bh = {};
             if (live) bh = inter_aabb_t<FAST, true>(ray, rr, set_box(S));
-            ch = trace_dda_coop<COOP_CLOSEST, FAST, GRIDS == 1>(live && bh.v, ray, bh, S, defer);
+            ch = trace_dda_coop<COOP_CLOSEST, FAST, GRIDS == 1>(live && bh.v, ray, rr, bh, S, defer);
         } else if (live) {
             const BoxHit bh = inter_aabb_t<FAST, true>(ray, rr, set_box(S));
             if (bh.v) ch = trace_dda<SPHERES, false, TRI_A10, FAST, GRIDS == 1>(ray, bh, S, defer);
@@ -308,7 +308,7 @@ PT_DEV void direct_all(const FusedArgs& A, Poi& poi, int32_t& seed, float4& acc,
                 BoxHit bh = {};
                 if (live) bh = inter_aabb_t<FAST, true>(sh, rr, set_box(S));
                 walked = live && bh.v;
-                ch = trace_dda_coop<COOP_ANY, FAST, GRIDS == 1>(walked, sh, bh, S, defer);
+                ch = trace_dda_coop<COOP_ANY, FAST, GRIDS == 1>(walked, sh, rr, bh, S, defer);
             } else if (live) {
                 const BoxHit bh = inter_aabb_t<FAST, true>(sh, rr, set_box(S));
                 if (bh.v) {

@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) k_closestMesh(uint32_t total, PoiAoS* poi
         }
     }
     bool unused = false;
-    const Hit ch = trace_dda_coop<COOP_CLOSEST, false, false>(want, ray, bh, mk_set(prims, off, bound8, n, 0u), unused);
+    const Hit ch = trace_dda_coop<COOP_CLOSEST, false, false>(want, ray, RayRcp{0.0f, 0.0f, 0.0f}, bh, mk_set(prims, off, bound8, n, 0u), unused);
     if (!want || ch.idx == UINT32_MAX) return;
     rays[id].maxt = ch.t;
     const f3 p = fma3(ch.t, ray.d, ray.o);   // getPoint, code.cl:87
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) k_anyhitMesh(uint32_t total, RayAoS* shad
         }
     }
     bool unused = false;
-    const Hit ch = trace_dda_coop<COOP_ANY_FIRST, false, false>(want, sh, bh, mk_set(prims, off, bound8, n, 0u), unused);
+    const Hit ch = trace_dda_coop<COOP_ANY_FIRST, false, false>(want, sh, RayRcp{0.0f, 0.0f, 0.0f}, bh, mk_set(prims, off, bound8, n, 0u), unused);
     uint8_t mr = 0;
     if (want && ch.idx != UINT32_MAX) {
         sh.mint = ch.t;

@@ -119,6 +119,7 @@ inline size_t prepared_planes_bytes(uint32_t count) { return 64 + ((size_t)count
 __host__ __device__ inline size_t prepared_planes_offset(uint32_t count) { return ((size_t)count * 48 + ((size_t)count + kTriGroup - 1) / kTriGroup * 16 + 63) & ~(size_t)63; }
 
 // ---- uniform-grid build on the device (pt_grid_build.hip) -------------------------------------------
+constexpr uint32_t kMaxCellSlots = 1u << 24;        // slots ONE cell of a grid with n > 1 may hold: the shared-test walk packs a slot's place in its cell into 24 bits (pt_trace_coop.hpp)
 constexpr uint64_t kMaxGridSlots = 0x7FFFFFFFull;   // (cell, primitive) slots one grid may hold: the sort and every consumer index them with 31 bits
 hipError_t grid_build(hipStream_t s, int kind, const double* prims, uint32_t count, const double bounds6[6], uint32_t n,
                       uint32_t* offsets, uint32_t** order_out, uint32_t* total, uint64_t* slots_needed);

@@ -328,7 +328,7 @@ PT_DEV bool den_window(float v) { const float a = __builtin_fabsf(v); return a >
 // The slab width delta = (hi - lo) / n and 1 / delta depend on the set alone: the host computes them once (GridArgs::delta / rdelta,
 // correctly rounded, which is what div_exact3 / rcp_refined give inside their windows; GridArgs::walk_ok says the windows hold).
 template <bool FAST>
-PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint32_t n, float delta, float rdelta, bool& defer) {
+PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint32_t n, float delta, float rdelta, float rd, bool& defer) {   // rd = rcp_refined(d): the ray's, made once (RayRcp)
     if (!FAST) return axis_setup(o, d, tmin, lo, hi, n);
     Axis a;
     const float x = cl_fma(tmin, d, o);                    // code.cl:698
@@ -339,7 +339,6 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     const bool fwd = d >= 0;
     a.dslab = fwd ? 1 : -1;
     a.limit = fwd ? (int)n : -1;
-    const float rd = rcp_refined(d);
     a.dt = div_exact3(delta, cl_fabs(d), cl_fabs(rd));   // rcp_refined is odd in d: every step is sign-symmetric under RNE
     const float xnext = cl_fma((float)(a.slab + (fwd ? 1 : 0)), delta, lo);   // code.cl:706
     const float num1 = xnext - o;
@@ -579,9 +578,9 @@ PT_DEV Hit trace_dda(const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& 
     int sx, sy, sz;
     {
         if (FAST) defer = defer || S.walk_ok == 0u;
-        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, S.delta[0], S.rdelta[0], defer);
-        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, S.delta[1], S.rdelta[1], defer);
-        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, S.delta[2], S.rdelta[2], defer);
+        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, S.delta[0], S.rdelta[0], FAST ? rcp_refined(ray.d.x) : 0.0f, defer);
+        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, S.delta[1], S.rdelta[1], FAST ? rcp_refined(ray.d.y) : 0.0f, defer);
+        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, S.delta[2], S.rdelta[2], FAST ? rcp_refined(ray.d.z) : 0.0f, defer);
         tnx = ax.tnext; tny = ay.tnext; tnz = az.tnext;
         dtx = ax.dt; dty = ay.dt; dtz = az.dt;
         sx = ax.slab; sy = ay.slab; sz = az.slab;

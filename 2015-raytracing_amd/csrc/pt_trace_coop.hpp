@@ -4,19 +4,34 @@
 // against a mesh in an n^3 grid) a quarter of the lanes hold a triangle at any time, and a 60-instruction test issues for the whole
 // wave however few do: the walk is VALU-issue-bound at 24 % lane utilisation (cornell_teapot3).
 //
-// Here the walk alternates two wave-wide phases:
-//   A  every live lane steps its own DDA through EMPTY cells until it stands in a cell that holds primitives (or has left the grid);
-//   B  the (ray, primitive) pairs of ALL those cells -- lane L contributes end_L - i_L of them -- are laid out back to back
-//      (a wave prefix sum) and tested 64 at a time by whichever lanes are free, each tester fetching "its" ray, maxt and cell window
-//      from the owner's REGISTERS by ds_bpermute.  Hits go back to the owner through one LDS atomic: a 64-bit minimum over (t, primitive index).
-// A lane's ray meets exactly the cells, and in each cell exactly the primitives with exactly the [cmin, cmax] windows, of the
-// reference's nested loops (A10 code.cl:937-1070, 1195-1321); only WHO evaluates a test and in which order changes.  Order does not
-// matter: inside a cell the reference keeps the hit with the smallest t, the first one among equals (strict <, code.cl:1017-1026) --
-// the minimum of (t, index) -- and closes the walk at the first cell that produced one.  For shadow rays only "was anything hit with
-// t < maxt" survives the fused kernel (sceneRender compares mint with maxt, code.cl:1339), so any hit will do there; the
-// kernel-by-kernel path stores the shadow Ray and asks for the first hit in list order: the minimum of the index alone.
-// t values are compared through the usual order-preserving map of IEEE bits to unsigned, after t + 0 (a -0 and a +0 are the same
-// distance to the reference's <); the winner's own t / beta / gamma bits travel through three more LDS words.
+// Here a walk alternates two wave-wide phases:
+//   A  every live lane steps its own DDA along its WHOLE way through the grid -- to where the ray leaves it, or to the first cell that starts
+//      at or beyond the ray's end -- and leaves one record {first slot, count, cmin, cmax} per cell that holds primitives in the wave's
+//      record pool (64 records in LDS; a lane that finds the pool full keeps its cell for the next sweep);
+//   B  the (ray, primitive) pairs of ALL those records are laid out back to back (a wave prefix sum over the records' counts) and tested 64
+//      at a time by whichever lanes are free, each tester fetching "its" ray and its end from the owner's REGISTERS by ds_bpermute and the
+//      cell's window from the record.  Hits go back to the owner through one LDS atomic: a 64-bit minimum over (t, record, slot in the cell).
+// Round 3's walk pooled one cell per lane and phase: the lanes of a wave need different numbers of cells (one and a half on average, five
+// for the slowest of a wave), so a walk took five phases whose later rounds tested a handful of pairs -- 23 of 64 on average (profiles/
+// r4_work/trips_teapot3_r3walk.txt).  With the whole way pooled a walk is one sweep, seldom two.
+//
+// A lane's ray meets exactly the cells, and in each cell exactly the primitives with exactly the [cmin, cmax] windows, of the reference's
+// nested loops (A10 code.cl:937-1070, 1195-1321) -- plus, for a ray that hits, the cells BEHIND the hit the reference never reaches.
+// Nothing they yield survives: the reference closes the walk at the first cell that produced a hit and keeps, inside it, the hit with the
+// smallest t, the first one among equals (strict <, code.cl:1017-1026); cells are met in increasing t (a later cell's window starts where
+// the earlier one ends, and a hit lies inside its cell's window), so that hit IS the minimum of (t, record, slot) over everything the lane
+// pooled: a later cell can tie on t at best, and then loses on its record number (a lane's records are numbered in the order it met the
+// cells).  For shadow rays only "was anything hit with t < maxt" survives the fused kernel (sceneRender compares mint with maxt,
+// code.cl:1339), so any hit will do there; the kernel-by-kernel path stores the shadow Ray and asks for the first hit in list order of the
+// first cell that has one: the minimum of (record, slot) alone.  t values are compared through the usual order-preserving map of IEEE bits
+// to unsigned, after t + 0 (a -0 and a +0 are the same distance to the reference's <).  The winner's t / beta / gamma are not passed back:
+// its owner runs the reference's test on it once more -- same operands, same operations, same bits -- which costs one test per walk and
+// saves three exchange rows per wave (the 768 bytes that keep six blocks on a CU).
+//
+// How far ahead of the verdict a lane pools (measured with a cap on the cells per sweep, cornell_teapot3 / cornell_teapot 1080p x 16, ms per pass):
+// 1 / 2 / 3 / 4 / its whole way = 33.6 / 28.9 / 27.1 / 26.5 / 26.4 and 23.2 / 20.0 / 18.8 / 18.4 / 18.2 (round 3's one-cell walk without a pool:
+// 29.1 / 19.9).  A ray that hits in its first cell has no use for the cells behind it -- the whole way tests 54 % more pairs than the reference
+// makes -- and still it is the sweeps that cost, not the pairs.
 //
 // Requires EVERY lane of the wave to enter (lanes without a ray pass want = false): the prefix sums are DPP row operations.
 #pragma once
@@ -28,23 +43,14 @@
 
 namespace pt {
 
-// One wave's exchange area in the block's dynamic LDS: CW_ROWS rows of 64 words, [row][lane]; 1.5 KB per wave, 6 KB per block, at
-// the start of the dynamic segment (the staged cell-offset tables follow: launch_fused).
-// The owner's maxt, cell window and pair base are NOT rows: they reach a tester through ds_bpermute from the owner's registers (four
-// rows = 4 KB of LDS per block less, and cornell_teapot3 853 -> 859 Msamples/s) -- and since round 3 neither is its ray (six rows more:
-// what lets six blocks share a CU's LDS, pt_kernels_fused.hip PT_FUSED_WAVES_GRIDS).
-#ifndef PT_COOP_RUNNING_CELL
-#define PT_COOP_RUNNING_CELL 1   // phase A carries the cell index and the three slab indices (packed) along instead of re-deriving the index per step
-#endif
-#ifndef PT_COOP_RAY_BPERMUTE
-#define PT_COOP_RAY_BPERMUTE 1   // the owner's ray reaches a tester by ds_bpermute from the owner's registers too: six rows (6 KB per block) less
-#endif
-#if PT_COOP_RAY_BPERMUTE
-enum { CW_OWN = 0, CW_T, CW_BETA, CW_GAMMA, CW_KEY /* two rows: 64 x u64 */, CW_ROWS = 6 };
-#else
-enum { CW_OX = 0, CW_OY, CW_OZ, CW_DX, CW_DY, CW_DZ, CW_OWN, CW_T, CW_BETA, CW_GAMMA, CW_KEY /* two rows: 64 x u64 */, CW_ROWS = 12 };
-#endif
-constexpr uint32_t kCoopWordsPerBlock = 4u * CW_ROWS * 64u;
+// One wave's exchange area in the block's dynamic LDS, [row][lane] rows of 64 words at the start of the dynamic segment (the staged
+// cell-offset tables follow: launch_fused): the owner marks of a round, the 64 keys (two rows), the record pool (64 records of four words:
+// four rows) and the pool's counter.  The owner's ray and end reach a tester through ds_bpermute from the owner's registers.
+enum { CW_OWN = 0, CW_KEY /* two rows: 64 x u64 */, CW_POOL = 3 /* four rows: 64 x {first, count | owner << 24, cmin, cmax} */, CW_COUNT = 7 /* one word (a 16-byte row) */ };
+constexpr uint32_t kCoopWordsPerWave = 7u * 64u + 4u;
+constexpr uint32_t kCoopWordsPerBlock = 4u * kCoopWordsPerWave;
+constexpr uint32_t kCoopPool = 64;               // records per sweep
+constexpr uint32_t kCoopMaxCell = kMaxCellSlots; // slots one cell may hold (the key packs a slot's place in its cell into 24 bits): check_grid refuses more
 
 template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
 PT_DEV uint32_t dpp_or0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND); }
@@ -89,7 +95,7 @@ PT_DEV uint32_t t_key(float t) {
 enum CoopMode { COOP_CLOSEST = 0, COOP_ANY = 1, COOP_ANY_FIRST = 2 };
 
 template <int MODE, bool FAST, bool LDS_TABLES>
-PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const GridArgs& S, bool& defer) {
+PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const BoxHit& bh, const GridArgs& S, bool& defer) {
     constexpr bool ANY = MODE == COOP_ANY;
     Hit ch;
     ch.idx = UINT32_MAX;
@@ -108,47 +114,36 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
                                     // segment loop and kept alive -- in scratch, the one register the allocator had nowhere else to put
 #endif
     const uint32_t lane = tid & 63u;
-    const uint32_t wbase = (tid >> 6) * (CW_ROWS * 64u);
+    const uint32_t wbase = (tid >> 6) * kCoopWordsPerWave;
 #define CW_MINE(row) pt_lds_dyn[wbase + (uint32_t)(row) * 64u + lane]
 #define CW_OF(row, l) pt_lds_dyn[wbase + (uint32_t)(row) * 64u + (l)]
     unsigned long long* const keys = (unsigned long long*)&pt_lds_dyn[wbase + (uint32_t)CW_KEY * 64u];
+    uint4* const pool = (uint4*)&pt_lds_dyn[wbase + (uint32_t)CW_POOL * 64u];
+    uint32_t* const pool_count = &pt_lds_dyn[wbase + (uint32_t)CW_COUNT * 64u];
     const unsigned long long kNone = ~0ull;
 
     float tnx = 0.0f, tny = 0.0f, tnz = 0.0f, dtx = 0.0f, dty = 0.0f, dtz = 0.0f;
-    int sx = 0, sy = 0, sz = 0;
     const uint32_t zs = S.n * S.n, ys = S.n;   // n <= 1024 (check_grid): 24-bit multiplies are exact
-#if PT_COOP_RUNNING_CELL
     const uint32_t last = S.n - 1u;
     uint32_t cell = 0u, pk = 0u;
-#else
-    const int nn = (int)S.n;
-#endif
     const bool fwx = ray.d.x >= 0, fwy = ray.d.y >= 0, fwz = ray.d.z >= 0;   // code.cl:701-705: d >= 0 ? +1, n : -1, -1
     float cmin = 0.0f, cmax = 0.0f;
     uint32_t i = 0u, end = 0u;
     bool alive = want && !(bh.tmin >= ray.maxt);
     if (want) {
         bool dfr = FAST && S.walk_ok == 0u;
-        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, S.delta[0], S.rdelta[0], dfr);
-        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, S.delta[1], S.rdelta[1], dfr);
-        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, S.delta[2], S.rdelta[2], dfr);
+        const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, S.delta[0], S.rdelta[0], rr.x, dfr);
+        const Axis ay = axis_setup_t<FAST>(ray.o.y, ray.d.y, bh.tmin, S.bound[1], S.bound[5], S.n, S.delta[1], S.rdelta[1], rr.y, dfr);
+        const Axis az = axis_setup_t<FAST>(ray.o.z, ray.d.z, bh.tmin, S.bound[2], S.bound[6], S.n, S.delta[2], S.rdelta[2], rr.z, dfr);
         defer = defer || dfr;
         tnx = ax.tnext; tny = ay.tnext; tnz = az.tnext;
         dtx = ax.dt; dty = ay.dt; dtz = az.dt;
-        sx = ax.slab; sy = ay.slab; sz = az.slab;
         cmin = bh.tmin;
         cmax = cl_min(cl_min(tnx, tny), tnz);
-#if PT_COOP_RUNNING_CELL
-        cell = __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx;
-        pk = (uint32_t)sx | (uint32_t)sy << 10 | (uint32_t)sz << 20;
+        // the slab indices packed ten bits each (0 <= slab < n <= 1024 while the ray is inside) and the cell index carried along
+        cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
+        pk = (uint32_t)ax.slab | (uint32_t)ay.slab << 10 | (uint32_t)az.slab << 20;
         cell_range<LDS_TABLES>(S, off, cell, i, end);
-#else
-        cell_range<LDS_TABLES>(S, off, __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx, i, end);
-#endif
-#if !PT_COOP_RAY_BPERMUTE
-        CW_MINE(CW_OX) = __float_as_uint(ray.o.x); CW_MINE(CW_OY) = __float_as_uint(ray.o.y); CW_MINE(CW_OZ) = __float_as_uint(ray.o.z);
-        CW_MINE(CW_DX) = __float_as_uint(ray.d.x); CW_MINE(CW_DY) = __float_as_uint(ray.d.y); CW_MINE(CW_DZ) = __float_as_uint(ray.d.z);
-#endif
     }
     keys[lane] = kNone;
     // one past the last slot of the set: a (ray, primitive) pair is only ever formed below it (a table that lies cannot send a load astray)
@@ -160,14 +155,23 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
     }
 
     for (;;) {
-        // ---- phase A: through empty cells (code.cl:1028-1066's step, unchanged)
+        if (lane == 0u) *pool_count = 0u;
+        wave_fence();
         pt_count(PC_GRID_PHASES + PCK);
-        while (alive && i == end) {
+        // ---- phase A: the lane's whole way through the grid (code.cl:1028-1066's step, unchanged), one record per cell with a list.
+        // Measured and not kept: the walk's state kept out of phase B by walking the way again after a full pool (no spill
+        // in the 96-register build, 5 % slower: pools do fill); record slots handed out by a ballot instead of the LDS atomic, and the axis step
+        // as selects (both bit-identical, 8-10 % slower: the compiler's exec-mask bookkeeping for the loop grew by a quarter).
+        while (alive) {
             pt_count(PC_GRID_A_STEPS + PCK); pt_count(PC_GRID_A_LANE_STEPS + PCK, true);
+            if (i != end) {
+                const uint32_t slot = __hip_atomic_fetch_add(pool_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (slot >= kCoopPool) break;   // the pool is full: this cell is the first record of the lane's next sweep
+                pool[slot] = make_uint4(i, (end - i) | lane << 24, __float_as_uint(cmin), __float_as_uint(cmax));
+                i = end;
+            }
             const float t = cmax;
             bool out;
-#if PT_COOP_RUNNING_CELL
-            // the slab indices packed ten bits each (0 <= slab < n <= 1024 while the ray is inside) and the cell index carried along:
             // "the step leaves the grid" (code.cl:701-705's limit, n or -1) is "the slab stepped FROM is n - 1 or 0"
             if (t == tnx) {
                 tnx += dtx;
@@ -185,105 +189,86 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const BoxHit& bh, const Gri
                 pk += fwz ? 1u << 20 : 0u - (1u << 20);
                 cell += fwz ? zs : 0u - zs;
             }
-#else
-            if (t == tnx) {
-                tnx += dtx;
-                sx += fwx ? 1 : -1;
-                out = t >= bh.tmax || sx == (fwx ? nn : -1);
-            } else if (t == tny) {
-                tny += dty;
-                sy += fwy ? 1 : -1;
-                out = t >= bh.tmax || sy == (fwy ? nn : -1);
-            } else {
-                tnz += dtz;
-                sz += fwz ? 1 : -1;
-                out = t >= bh.tmax || sz == (fwz ? nn : -1);
-            }
-#endif
             // ... or the cell starts at or beyond the ray's end: a hit needs cmin <= t < maxt, and cmin only grows from here
             // (the reference walks on to the grid's far side rejecting every hit; nothing it computes there survives)
             if (out || t >= ray.maxt) { alive = false; break; }
             cmin = t;
             cmax = cl_min(cl_min(tnx, tny), tnz);
-#if PT_COOP_RUNNING_CELL
             cell_range<LDS_TABLES>(S, off, cell, i, end);
-#else
-            cell_range<LDS_TABLES>(S, off, __umul24((uint32_t)sz, zs) + __umul24((uint32_t)sy, ys) + (uint32_t)sx, i, end);
-#endif
         }
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
-        // ---- phase B: every pair (owner lane, primitive of its cell), 64 at a time
-        const uint32_t cnt = alive ? end - i : 0u;
+        wave_fence();
+        uint32_t n_rec = __builtin_amdgcn_readfirstlane(*pool_count);
+        if (n_rec == 0u) break;   // (no record: every lane's walk is over)
+        n_rec = n_rec < kCoopPool ? n_rec : kCoopPool;
+        // ---- phase B: every pair (record, slot of its cell), 64 at a time.  Lane r speaks for record r.
+        const uint32_t cnt = lane < n_rec ? pool[lane].y & (kCoopMaxCell - 1u) : 0u;
         const uint32_t incl = wave_scan_add(cnt), excl = incl - cnt;
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
         pt_count(PC_GRID_PAIRS + PCK, false, total);
         for (uint32_t base = 0u; base < total; base += 64u) {
             pt_count(PC_GRID_ROUNDS + PCK);
-            // who owns pair base + lane: owners mark the first pair of theirs inside this window, a prefix maximum spreads the mark
+            // which record pair base + lane belongs to: records mark the first pair of theirs inside this window, a prefix maximum spreads the mark
             CW_MINE(CW_OWN) = 0u;
             if (cnt != 0u && excl < base + 64u && incl > base) CW_OF(CW_OWN, (excl > base ? excl : base) - base) = lane + 1u;
             wave_fence();
             const uint32_t mark = wave_scan_max(CW_MINE(CW_OWN));
             const uint32_t p = base + lane;
-            // pair p of the wave is primitive (i - excl) + p of its owner's set.  Every lane asks (a lane without a pair asks lane 0 and drops the answer): ds_bpermute reads the owners' registers
-            const int oaddr = (int)((mark != 0u ? mark - 1u : 0u) << 2);
-            const float omax = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(ray.maxt)));
-            const float ocmin = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(cmin)));
-            const float ocmax = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(cmax)));
-            const uint32_t oibx = (uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)(i - excl));
-#if PT_COOP_RAY_BPERMUTE
+            const uint32_t r = mark != 0u ? mark - 1u : 0u;   // (a lane without a pair asks record 0 and drops the answers)
+            const uint32_t rexcl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r << 2), (int)excl);
+            const uint4 rec = pool[r];
+            const uint32_t o = rec.y >> 24;
+            const int oaddr = (int)(o << 2);
             auto pull = [&](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(oaddr, (int)__float_as_uint(v))); };
+            const float omax = pull(ray.maxt);
             const f3 ro = mk3(pull(ray.o.x), pull(ray.o.y), pull(ray.o.z));
             const f3 rd = mk3(pull(ray.d.x), pull(ray.d.y), pull(ray.d.z));
-#endif
             if (p < total && mark != 0u) {
-                const uint32_t o = mark - 1u;
-                const uint32_t prim = oibx + p;
+                const uint32_t j = p - rexcl;
+                const uint32_t prim = rec.x + j;
                 if (prim < nslots) {
-#if !PT_COOP_RAY_BPERMUTE
-                    const f3 ro = mk3(__uint_as_float(CW_OF(CW_OX, o)), __uint_as_float(CW_OF(CW_OY, o)), __uint_as_float(CW_OF(CW_OZ, o)));
-                    const f3 rd = mk3(__uint_as_float(CW_OF(CW_DX, o)), __uint_as_float(CW_OF(CW_DY, o)), __uint_as_float(CW_OF(CW_DZ, o)));
-#endif
                     const float4* __restrict__ q = prims + 3u * (size_t)prim;
                     float tt, bb, gg;
-                    if (tri_test<TRI_A10, FAST>(ro, rd, ocmin, ocmax, q[0], q[1], q[2], tt, bb, gg) && tt < omax) {
+                    if (tri_test<TRI_A10, FAST>(ro, rd, __uint_as_float(rec.z), __uint_as_float(rec.w), q[0], q[1], q[2], tt, bb, gg) && tt < omax) {
                         if (ANY) keys[o] = 0ull;
                         else {
-                            // COOP_ANY_FIRST: the lowest primitive index wins whatever its t
-                            const unsigned long long mk = MODE == COOP_ANY_FIRST ? (unsigned long long)prim : (((unsigned long long)t_key(tt) << 32) | prim);
+                            // (record, slot): a lane's records are numbered in the order it met the cells, so the first cell wins a tie on t and, inside
+                            // a cell, the lower slot; COOP_ANY_FIRST: the first cell with a hit, its lowest slot, whatever the t
+                            const uint32_t lo = r << 24 | j;
+                            const unsigned long long mk = MODE == COOP_ANY_FIRST ? (unsigned long long)lo : (((unsigned long long)t_key(tt) << 32) | lo);
                             __hip_atomic_fetch_min(&keys[o], mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            // the pair that holds its owner's minimum hands over its own t / beta / gamma bits.  Every lane's minimum of
-                            // this round is in before any lane's read below (one wave: the LDS runs its instructions in order)
-                            wave_fence();
-                            if (keys[o] == mk) {
-                                CW_OF(CW_T, o) = __float_as_uint(tt);
-                                CW_OF(CW_BETA, o) = __float_as_uint(bb);
-                                CW_OF(CW_GAMMA, o) = __float_as_uint(gg);
-                            }
                         }
                     }
                 }
             }
         }
         wave_fence();
-        // the cell is done: a hit inside it ends the walk (code.cl:768-771), else the DDA steps on
-        if (alive) {
-            if (keys[lane] != kNone) alive = false;
-            else i = end;
-        }
-    }
-    if (want) {
+        // a hit anywhere on the lane's way ends its walk (code.cl:768-771: the first cell that produced one closes it)
         const unsigned long long k = keys[lane];
-        if (k != kNone) {
-            ch.idx = (uint32_t)k;
-            if (!ANY) {
-                ch.t = __uint_as_float(CW_MINE(CW_T));
-                if (MODE == COOP_CLOSEST) {
-                    ch.beta = __uint_as_float(CW_MINE(CW_BETA));
-                    ch.gamma = __uint_as_float(CW_MINE(CW_GAMMA));
-                }
+        const bool got = want && k != kNone;
+        if (got) alive = false;
+        if (!ANY) {
+            // the winner: its slot and its cell's window, out of the record while the pool still holds it (the window parks in beta / gamma)
+            if (got && ch.idx == UINT32_MAX) {
+                const uint32_t lo = (uint32_t)k;
+                const uint4 rec = pool[lo >> 24];
+                ch.idx = rec.x + (lo & (kCoopMaxCell - 1u));
+                ch.beta = __uint_as_float(rec.z);
+                ch.gamma = __uint_as_float(rec.w);
             }
-        }
+        } else if (got) ch.idx = 0u;
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+    }
+    if (!ANY && __builtin_amdgcn_ballot_w64(ch.idx != UINT32_MAX) != 0ull) {
+        // the winner once more, by its owner: the reference's test on the same operands gives the same t / beta / gamma
+        const bool got = ch.idx != UINT32_MAX;
+        if (got && ch.idx < nslots) {
+            const float4* __restrict__ q = prims + 3u * (size_t)ch.idx;
+            float tt, bb, gg;
+            (void)tri_test<TRI_A10, FAST>(ray.o, ray.d, ch.beta, ch.gamma, q[0], q[1], q[2], tt, bb, gg);
+            ch.t = tt;
+            ch.beta = bb;
+            ch.gamma = gg;
+        } else if (got) ch.idx = UINT32_MAX;   // (a table that lies: no pair was formed at or beyond nslots, so no key can name one)
     }
 #undef CW_MINE
 #undef CW_OF
