@@ -122,6 +122,14 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
     uint32_t* const pool_count = &pt_lds_dyn[wbase + (uint32_t)CW_COUNT * 64u];
     const unsigned long long kNone = ~0ull;
 
+    // the staged table's place in the block's LDS, pinned in a scalar register: left to itself the compiler, short of SGPRs, re-loaded it from the
+    // kernel arguments inside the stepping loop -- a scalar-memory round trip ahead of every step's LDS read
+    uint32_t toff = S.lds_off;
+    asm volatile("" : "+s"(toff));
+    auto range = [&](uint32_t c, uint32_t& first, uint32_t& past) {
+        if (LDS_TABLES) { first = pt_lds_dyn[toff + c]; past = pt_lds_dyn[toff + c + 1u]; }
+        else { first = off[c]; past = off[c + 1u]; }
+    };
     float tnx = 0.0f, tny = 0.0f, tnz = 0.0f, dtx = 0.0f, dty = 0.0f, dtz = 0.0f;
     const uint32_t zs = S.n * S.n, ys = S.n;   // n <= 1024 (check_grid): 24-bit multiplies are exact
     const uint32_t last = S.n - 1u;
@@ -143,14 +151,14 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
         // the slab indices packed ten bits each (0 <= slab < n <= 1024 while the ray is inside) and the cell index carried along
         cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
         pk = (uint32_t)ax.slab | (uint32_t)ay.slab << 10 | (uint32_t)az.slab << 20;
-        cell_range<LDS_TABLES>(S, off, cell, i, end);
+        range(cell, i, end);
     }
     keys[lane] = kNone;
     // one past the last slot of the set: a (ray, primitive) pair is only ever formed below it (a table that lies cannot send a load astray)
     uint32_t nslots = S.nslots;
     if (nslots == 0u) {
         uint32_t unused_;
-        cell_range<LDS_TABLES>(S, off, zs * S.n - 1u, unused_, nslots);
+        range(zs * S.n - 1u, unused_, nslots);
         nslots = __builtin_amdgcn_readfirstlane(nslots);
     }
 
@@ -160,8 +168,9 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
         pt_count(PC_GRID_PHASES + PCK);
         // ---- phase A: the lane's whole way through the grid (code.cl:1028-1066's step, unchanged), one record per cell with a list.
         // Measured and not kept: the walk's state kept out of phase B by walking the way again after a full pool (no spill
-        // in the 96-register build, 5 % slower: pools do fill); record slots handed out by a ballot instead of the LDS atomic, and the axis step
-        // as selects (both bit-identical, 8-10 % slower: the compiler's exec-mask bookkeeping for the loop grew by a quarter).
+        // in the 96-register build, 5 % slower: pools do fill); record slots handed out by a ballot instead of the LDS atomic (bit-identical,
+        // 10 % slower: the compiler's exec-mask bookkeeping for the loop grew by a quarter); "anything ahead?" bits per cell and octant that
+        // end a walk with only empty cells left (-18 % lane steps, 5 % slower: one more test and register in this loop).
         while (alive) {
             pt_count(PC_GRID_A_STEPS + PCK); pt_count(PC_GRID_A_LANE_STEPS + PCK, true);
             if (i != end) {
@@ -173,28 +182,23 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
             const float t = cmax;
             bool out;
             // "the step leaves the grid" (code.cl:701-705's limit, n or -1) is "the slab stepped FROM is n - 1 or 0"
-            if (t == tnx) {
-                tnx += dtx;
-                out = t >= bh.tmax || (pk & 1023u) == (fwx ? last : 0u);
-                pk += fwx ? 1u : ~0u;
-                cell += fwx ? 1u : ~0u;
-            } else if (t == tny) {
-                tny += dty;
-                out = t >= bh.tmax || ((pk >> 10) & 1023u) == (fwy ? last : 0u);
-                pk += fwy ? 1u << 10 : 0u - (1u << 10);
-                cell += fwy ? ys : 0u - ys;
-            } else {
-                tnz += dtz;
-                out = t >= bh.tmax || (pk >> 20) == (fwz ? last : 0u);
-                pk += fwz ? 1u << 20 : 0u - (1u << 20);
-                cell += fwz ? zs : 0u - zs;
-            }
+            // The reference's if / else-if / else (x, then y, then z: code.cl:1028-1066): the three branches only pick the axis' values; the
+            // comparison and the updates happen once, behind them.  (Measured, cornell_teapot3 / cornell_teapot / own_gems ms per pass: every
+            // branch with its own compare and updates 25.9 / 17.9 / 11.8; all selects 25.1 / 17.1 / 11.3; this 24.7 / 17.2 / 11.7; the loop
+            // spelled without `break` is slower with either, 25.8-26.0.)
+            uint32_t fld, lim, dpk, dcell;
+            if (t == tnx) { tnx += dtx; fld = pk & 1023u; lim = fwx ? last : 0u; dpk = fwx ? 1u : ~0u; dcell = fwx ? 1u : ~0u; }
+            else if (t == tny) { tny += dty; fld = (pk >> 10) & 1023u; lim = fwy ? last : 0u; dpk = fwy ? 1u << 10 : 0u - (1u << 10); dcell = fwy ? ys : 0u - ys; }
+            else { tnz += dtz; fld = pk >> 20; lim = fwz ? last : 0u; dpk = fwz ? 1u << 20 : 0u - (1u << 20); dcell = fwz ? zs : 0u - zs; }
+            out = t >= bh.tmax || fld == lim;
+            pk += dpk;
+            cell += dcell;
             // ... or the cell starts at or beyond the ray's end: a hit needs cmin <= t < maxt, and cmin only grows from here
             // (the reference walks on to the grid's far side rejecting every hit; nothing it computes there survives)
             if (out || t >= ray.maxt) { alive = false; break; }
             cmin = t;
             cmax = cl_min(cl_min(tnx, tny), tnz);
-            cell_range<LDS_TABLES>(S, off, cell, i, end);
+            range(cell, i, end);
         }
         wave_fence();
         uint32_t n_rec = __builtin_amdgcn_readfirstlane(*pool_count);
