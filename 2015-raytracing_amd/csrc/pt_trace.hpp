@@ -210,11 +210,12 @@ PT_DEV bool slab1_fast(float lo, float hi, float o, float d, float r, BoxHit& h,
         t0 = div_exact3(lo - o, d, r);
         t1 = div_exact3(hi - o, d, r);
     } else {
-        const float n0 = lo - o, n1 = hi - o, q0 = n0 * r, q1 = n1 * r;
+        const float n0 = lo - o, n1 = hi - o;
 #if PT_PLAIN_DIV
         t0 = n0 / d;
         t1 = n1 / d;
 #else
+        const float q0 = n0 * r, q1 = n1 * r;
         t0 = __builtin_fmaf(__builtin_fmaf(-d, q0, n0), r, q0);
         t1 = __builtin_fmaf(__builtin_fmaf(-d, q1, n1), r, q1);
 #endif
@@ -254,12 +255,12 @@ PT_DEV BoxHit inter_aabb_t(const Ray& r, const RayRcp& q, const Box& b) {
         // 366-369, 381-384) say no exactly when the final pair does: one comparison, and the chains as v_max3_f32 / v_min3_f32.  Inside
         // the guard windows every quotient is finite, so the chain's leading min(inf, .) is the identity; the sign of a zero is invisible
         // to comparisons (slab1_fast).
-        auto quo = [](float num, float d, float rr) { const float q0 = num * rr; return __builtin_fmaf(__builtin_fmaf(-d, q0, num), rr, q0); };
         BoxHit h;
 #if PT_PLAIN_DIV
         const float x0 = (b.lo.x - r.o.x) / r.d.x, x1 = (b.hi.x - r.o.x) / r.d.x, y0 = (b.lo.y - r.o.y) / r.d.y, y1 = (b.hi.y - r.o.y) / r.d.y;
         const float z0 = (b.lo.z - r.o.z) / r.d.z, z1 = (b.hi.z - r.o.z) / r.d.z;
 #else
+        auto quo = [](float num, float d, float rr) { const float q0 = num * rr; return __builtin_fmaf(__builtin_fmaf(-d, q0, num), rr, q0); };
         const float x0 = quo(b.lo.x - r.o.x, r.d.x, q.x), x1 = quo(b.hi.x - r.o.x, r.d.x, q.x);
         const float y0 = quo(b.lo.y - r.o.y, r.d.y, q.y), y1 = quo(b.hi.y - r.o.y, r.d.y, q.y);
         const float z0 = quo(b.lo.z - r.o.z, r.d.z, q.z), z1 = quo(b.hi.z - r.o.z, r.d.z, q.z);

@@ -12,7 +12,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MIRT_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libmirt.so")  # override: A/B builds only
+# MIRT_CONTRACT=default: the library built for the reference's own build options (AMD's default 2.5-ulp division and 3-ulp sqrt: csrc/build.sh,
+# DESIGN.md section 2) instead of the correctly rounded contract; MIRT_LIB_PATH: an A/B build
+LIB_PATH = os.environ.get("MIRT_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libmirt_default.so" if os.environ.get("MIRT_CONTRACT") == "default" else "libmirt.so")
 
 MEM_READ_WRITE, MEM_WRITE_ONLY, MEM_READ_ONLY = 1, 2, 4
 MAX_LIGHTS, MAX_MESHES = 8, 16

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""tests/default_contract_check.py -- run by tests/test_default_contract.py in a process of its own (MIRT_CONTRACT=default, so that pyhost loads
+libmirt_default.so): the HIP path built for the reference's OWN build options -- program.build() without options (A10 code.js:599): AMD's default
+2.5-ulp division and 3-ulp sqrt -- against the reference's code.cl compiled the same way (oracle/_ref/a10_gfx950_default.hsaco), device against
+device, same seeds: every accumulator, seed and pixel.  Prints one JSON object per check; exits non-zero on the first difference, naming it."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as graft  # noqa: E402
+import a10_pass as A  # noqa: E402
+import ref_gpu as G  # noqa: E402
+from conftest import canon, load_fixture  # noqa: E402
+
+DEFAULT_HSACO = os.path.join(ROOT, "oracle", "_ref", "a10_gfx950_default.hsaco")
+SCENES = ["basic_32x24_r4", "cornell_32x24_r4", "triangles_32x24_r4", "twoLights_32x24_r4", "threeLights_32x24_r1", "cornell_official_64x48_r1",
+          "cornell_teapot3_32x24_r4", "own_flat_32x24_r4", "own_gems_48x36_r4", "own_studio_48x36_r4", "basic2_32x24_r4", "cornell_teapot_32x24_r4",
+          "cornell_teapot2_32x24_r4"]
+
+
+def first_difference(tag, got, want):
+    g, w = canon(got).ravel(), canon(want).ravel()
+    bad = np.flatnonzero(g != w)
+    if bad.size == 0:
+        return None
+    i = int(bad[0])
+    return f"{tag}: {bad.size} of {g.size} words differ; first at word {i}: ours 0x{int(g[i]):08x}, the reference's 0x{int(w[i]):08x}"
+
+
+def scenes(mirt, render, scene):
+    for name in SCENES:
+        fx, sc0 = load_fixture(name)
+        ps = scene.PackedScene(dict(sc0.d)).resized(480, 270, 16)
+        sc = A.Scene(ps.d)
+        seeds = A.make_seeds(sc.total_rays, seed_base=11)
+        k = G.GpuRefKernels(DEFAULT_HSACO)
+        st = A.PassState(sc, seeds)
+        ctx = mirt.Context(0)
+        fr = render.FusedRenderer(ctx, ps, seeds=seeds)
+        try:
+            for p in range(2):
+                A.run_pass(k, sc, st, bounces=8, init_acu=(p == 0))
+                fr.execute_render(bounces=8)
+            for tag, got, want in (("accumulators", fr.acu.read(np.float32), st.acu), ("seeds", fr.seeds.read(np.int32), st.seeds),
+                                   ("pixels", fr.pixel.read(np.uint8), st.pixel)):
+                d = first_difference(f"{name} {tag}", np.asarray(got), np.asarray(want))
+                if d:
+                    print(json.dumps({"check": "scenes", "scene": name, "ok": False, "difference": d}), flush=True)
+                    return False
+            print(json.dumps({"check": "scenes", "scene": name, "ok": True, "samples": 2 * sc.total_rays}), flush=True)
+        finally:
+            k.release()
+            fr.release()
+            ctx.destroy()
+    return True
+
+
+def headline(mirt, render, scene):
+    """BASELINE's headline frame at full size: 1920x1080 x 256 rays per pixel, depth 8 (530 841 600 samples)."""
+    import ctypes as C
+    base = scene.PackedScene(open(os.path.join(ROOT, "tests", "golden", "scene_cornell_1920x1080_r256.json")).read())
+    sc = A.Scene(base.d)
+    n, npix = sc.total_rays, sc.width * sc.height
+    ctx = mirt.Context(0)
+    fr = render.FusedRenderer(ctx, base, want_radiance=False)
+    seeds = fr.seeds.read(np.int32)
+    fr.execute_render(bounces=8, fresh=True)
+    ctx.finish()
+    k = G.GpuRefKernels(DEFAULT_HSACO)
+
+    class St:
+        pass
+    st = St()
+    st.rays, st.pois, st.shadow = G.DevBuf(n * 48), G.DevBuf(n * 64), G.DevBuf(n * 48)
+    st.acu, st.seeds, st.pixel = G.DevBuf(n * 16), G.DevBuf(n * 4), G.DevBuf(npix * 4)
+    st.passes = 1
+    st.seeds.upload(seeds)
+    del seeds
+    A.run_pass(k, sc, st, bounces=8)
+    ok = True
+    try:
+        for tag, got, want in (("pixels", fr.pixel.read(np.uint8), st.pixel.download(np.uint8, npix * 4)),
+                               ("seeds", fr.seeds.read(np.int32), st.seeds.download(np.int32, n))):
+            d = first_difference("headline " + tag, got, want)
+            if d:
+                print(json.dumps({"check": "headline", "ok": False, "difference": d}), flush=True)
+                return False
+        chunk = 1 << 26
+        for off in range(0, 4 * n, chunk):
+            m = min(chunk, 4 * n - off)
+            want = np.empty(m, np.float32)
+            G.chk(G.hip().hipMemcpy(want.ctypes.data_as(C.c_void_p), C.c_void_p(st.acu.ptr + 4 * off), 4 * m, 2), "D2H")
+            d = first_difference(f"headline accumulators [{off}, {off + m})", fr.acu.read(np.float32, count=m, offset=4 * off), want)
+            if d:
+                print(json.dumps({"check": "headline", "ok": False, "difference": d}), flush=True)
+                return False
+    finally:
+        for b in (st.rays, st.pois, st.shadow, st.acu, st.seeds, st.pixel):
+            b.free()
+        k.release()
+        fr.release()
+        ctx.destroy()
+    print(json.dumps({"check": "headline", "ok": ok, "samples": n}), flush=True)
+    return ok
+
+
+def main():
+    assert os.environ.get("MIRT_CONTRACT") == "default", "run with MIRT_CONTRACT=default"
+    graft.load_package()
+    from raytracing_amd.pyhost import mirt, render, scene
+    assert mirt.LIB_PATH.endswith("libmirt_default.so"), mirt.LIB_PATH
+    which = sys.argv[1:] or ["scenes", "headline"]
+    ok = True
+    if "scenes" in which:
+        ok = scenes(mirt, render, scene) and ok
+    if ok and "headline" in which:
+        ok = headline(mirt, render, scene) and ok
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
