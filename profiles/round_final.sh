@@ -15,7 +15,7 @@ timeout -k 10 300 python profiles/grid_split.py > "${OUT}/grid_split.txt" 2>&1 |
 timeout -k 10 900 bash profiles/run_profile.sh "${TAG}" > "${OUT}/run_profile.log" 2>&1 || exit 27
 timeout -k 10 600 bash profiles/scene_pmc.sh cornell_teapot3_32x24_r4 "${TAG}_teapot3" > "${OUT}/teapot3_pmc.txt" 2>&1 || exit 28
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "${OUT}/trace_teapot3" -- python3 bench.py --scene cornell_teapot3 --steps 2 --warmup 1 --no-cpu > "${OUT}/trace_teapot3.log" 2>&1 || exit 29
+rocprofv3 --kernel-trace --stats --output-format csv -d "${OUT}/trace_teapot3" -- python3 bench.py --scene cornell_teapot3 --steps 2 --warmup 1 --no-cpu --no-extras > "${OUT}/trace_teapot3.log" 2>&1 || exit 29
 SCENE=cornell_teapot3_32x24_r4 RPPS=16 timeout -k 10 600 python profiles/ref_gpu_bench.py > "${OUT}/ref_gpu_teapot3.txt" 2>&1 || exit 30
 timeout -k 10 600 python profiles/ref_gpu_bench.py > "${OUT}/ref_gpu_bench.txt" 2>&1 || exit 31
 echo "all done"

@@ -8,9 +8,9 @@ TAG="${1:-r1}"
 OUT="gpurun_out/prof_${TAG}"
 mkdir -p "${OUT}"
 export TMPDIR=/tmp
-BENCH=(python3 bench.py --steps 2 --warmup 1 --no-cpu --no-depth5)
+BENCH=(python3 bench.py --steps 2 --warmup 1 --no-cpu --no-depth5 --no-extras)
 # the stamp bench.py checks before it quotes these counters: the kernel sources of THIS tree and the workload of THIS command
-python3 -c 'import json, bench; print(json.dumps({"csrc_sha256": bench.csrc_sha256(), "workload": "cornell_1920x1080_r256_b8_n1", "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu --no-depth5"}))' > "${OUT}/stamp.json" || exit 10
+python3 -c 'import json, bench; print(json.dumps({"csrc_sha256": bench.csrc_sha256(), "workload": "cornell_1920x1080_r256_b8_n1", "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu --no-depth5 --no-extras"}))' > "${OUT}/stamp.json" || exit 10
 rocprofv3 --kernel-trace --stats --output-format csv -d "${OUT}/trace" -- "${BENCH[@]}" > "${OUT}/trace.log" 2>&1 || exit 11
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "${OUT}/pmc_fetch" -- "${BENCH[@]}" > "${OUT}/pmc_fetch.log" 2>&1 || exit 12
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "${OUT}/pmc_write" -- "${BENCH[@]}" > "${OUT}/pmc_write.log" 2>&1 || exit 13
