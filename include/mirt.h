@@ -172,7 +172,8 @@ typedef struct mirt_pass_desc {
     const mirt_light* lights;       /* [n_lights]                                                  */
     mirt_buf* material;             /* float4 per material (splitMaterialData, code.js:1774-1782)  */
     mirt_buf* seeds;                /* int32 per local ray, read-modify-write                      */
-    mirt_buf* acu;                  /* float4 per local ray, accumulated into (zero it first)      */
+    mirt_buf* acu;                  /* float4 per local ray, accumulated into (zero it first).  May be NULL for a frame's first pass
+                                     * (mirt_render_first_pass) that resolves its pixels itself: see below                       */
     mirt_buf* pixel;                /* optional: uchar4 per local pixel, written by copyToPixel    */
     mirt_buf* radiance;             /* optional: float4 per local pixel, un-scaled sequential sums */
 } mirt_pass_desc;
@@ -181,7 +182,14 @@ typedef struct mirt_pass_desc {
 MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
 /* The first pass of a frame with preRender's initAcu (A10 code.js:1078-1099, code.cl:448-456) folded in: `acu` is not read, every
  * accumulator starts at (0,0,0,0).  Saves the zeroing launch and half of the pass's memory traffic; results equal
- * mirt_zero(acu) + mirt_render_pass. */
+ * mirt_zero(acu) + mirt_render_pass.
+ * copyToPixel INSIDE the pass: when a pixel or radiance buffer is given and rays_per_pixel divides 256 (1, 4, 16, 64, 256: a block of
+ * 256 consecutive ray ids then holds whole pixels), every block sums its pixels' accumulators in LDS in copyToPixel's order (A10
+ * code.cl:1366-1386: sequential in i, from +0) and writes pixel / radiance itself -- no second kernel, no re-read of the accumulators.
+ * Then, and only then, `acu` may be NULL: nothing per ray but the seed touches memory (8 B per sample + 20 B per pixel) and the
+ * 16 bytes per ray are never allocated; with `acu` given it is written as before (what a second progressive pass needs).  Results
+ * are bit-identical either way.  In this mode the optimistic / exact kernel pair hands over whole blocks of 256 samples
+ * (mirt_pass_deferred counts them as such).  MIRT_INPASS_RESOLVE=0 in the environment keeps the separate copyToPixel. */
 MIRT_API int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
 /* Two ways to run the pass, identical results.  Default: the optimistic pair -- a kernel whose divisions are 3-operation
  * forms proven bit-exact inside a guard window (exhaustively, on the device: profiles/r1_divcheck_exhaustive.txt), plus the
