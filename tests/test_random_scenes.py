@@ -102,6 +102,12 @@ def test_random_scene_all_paths_agree(ctx, pkg, seed):
         assert np.array_equal(fr.seeds.read(np.int32), st.seeds)
         assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), st.pixel)
         fr.release()
+        # the same frame from the pass that resolves its own pixels, without a per-ray accumulator (rays per pixel 1 or 4: whole pixels per block)
+        fr = render.FusedRenderer(ctx, sc, seeds=seeds, keep_acu=False)
+        fr.execute_render(fresh=True)
+        assert np.array_equal(fr.seeds.read(np.int32), st.seeds), f"in-pass resolve, exact_only={exact_only}"
+        assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), st.pixel), f"in-pass resolve, exact_only={exact_only}"
+        fr.release()
     ctx.set_exact_only(False)
     gr = render.GranularRenderer(ctx, sc, seeds=seeds)
     gr.execute_render()
