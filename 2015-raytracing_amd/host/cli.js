@@ -1,7 +1,7 @@
 #!/usr/bin/env node
 // host/cli.js -- command-line front end of the JavaScript host.
 //   node cli.js pack   <scene.xml> <width> <height> <raysPerPixel>                 -> packed kernel inputs as JSON (stdout)
-//   node cli.js render <scene.xml> <width> <height> <raysPerPixel> <passes> <out.rgba> [--granular [--graph|--fusion]] [--device-grid] [--bounces N] [--seeds file.i32] [--gpus N [--force-rccl]]
+//   node cli.js render <scene.xml> <width> <height> <raysPerPixel> <passes> <out.rgba> [--granular [--graph|--fusion]] [--device-grid] [--no-acu] [--bounces N] [--seeds file.i32] [--gpus N [--force-rccl]]
 //                                                                                   -> RGBA8 frame, or a PPM when <out> ends in .ppm (+ <out>.radiance.f32) via the N-API addon
 //   node cli.js pack-frame <1|4|7> <mesh.json|mol.pdb|-> <width> <height> [nSlabs]  -> packed inputs of an Assign01/04/07 frame job (stdout)
 //   node cli.js frame      <1|4|7> <mesh.json|-> <width> <height> <nSlabs|0> <out.rgba>  -> RGBA8 frame of that job
@@ -37,7 +37,8 @@ if (cmd === "pack") {
 } else if (cmd === "render") {
   if (rest.length < 6) usage();
   const renderer = require("./renderer.js");
-  const opt = { granular: rest.includes("--granular"), graph: rest.includes("--graph"), fusion: rest.includes("--fusion"), deviceGrid: rest.includes("--device-grid"), bounces: 5, seeds: null };
+  const opt = { granular: rest.includes("--granular"), graph: rest.includes("--graph"), fusion: rest.includes("--fusion"), deviceGrid: rest.includes("--device-grid"), bounces: 5, seeds: null,
+                keepAcu: !rest.includes("--no-acu") };   // --no-acu: a one-pass frame without the 16 bytes per ray: the pass resolves its own pixels (mirt.h)
   let i;
   if ((i = rest.indexOf("--bounces")) >= 0) opt.bounces = +rest[i + 1];
   if ((i = rest.indexOf("--gpus")) >= 0) { opt.gpus = +rest[i + 1]; opt.forceRccl = rest.includes("--force-rccl"); }   // row tiles over N devices + gather

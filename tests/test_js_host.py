@@ -128,7 +128,7 @@ def test_webcl_surface_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fused", "granular", "granular+fusion", "fused+device-grid", "granular+device-grid"])
+@pytest.mark.parametrize("mode", ["fused", "fused+no-acu", "granular", "granular+fusion", "fused+device-grid", "granular+device-grid"])
 @pytest.mark.parametrize("name", sorted(OWN_SCENES))
 def test_node_render_matches_compiled_reference(tmp_path, name, mode):
     """scene.xml -> JS host -> N-API addon -> C ABI -> HIP kernels -> frame, against the compiled reference's frame.
@@ -142,6 +142,8 @@ def test_node_render_matches_compiled_reference(tmp_path, name, mode):
         args.append("--granular")
     if "device-grid" in mode:
         args.append("--device-grid")
+    if "no-acu" in mode:   # one pass, no per-ray accumulator: mirt_render_first_pass with acu == NULL resolves the frame inside the pass
+        args.append("--no-acu")
     if "fusion" in mode:   # the same enqueues, recognised by the runtime and run as one fused launch per pass (mirt_ctx_set_fusion)
         args.append("--fusion")
     log = run_node(*args, stderr=True)
