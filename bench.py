@@ -10,7 +10,10 @@ reference host for 1920x1080, rays_per_pixel = 256 (16x16 lens grid), one progre
 bounces after the primary hit; the reference hard-codes five, A10 code.js:1829 -- `--bounces 5` measures that,
 and the default run reports it beside the headline in "depth5"), seeds s[id] = 1 + (mix32(id ^ 0x9E3779B9)
 mod 2147483646) generated on the device.  One "step" is one such frame: initTrace .. 8 bounces .. copyToPixel,
-through mirt_render_pass (one fused launch + resolve).
+through mirt_render_first_pass: ONE fused launch that also resolves the pixels (round 4: no per-ray accumulator, 8 B per sample + 20 B per
+pixel of HBM traffic; --keep-acu: the accumulator written per ray as a progressive second pass would need it).  Beside the headline the
+default run reports the grid kernel (`grid_scene`: cornell_teapot3) and BASELINE configs 2 / 3 (`frames`), each with a roofline fraction and a
+bounded CPU baseline (--no-extras skips them).
 Inputs (scene buffers, seeds) are resident in HBM before the timed region.
 
 N > 1: one process per GPU; the frame is cut into N contiguous row tiles (ray ids stay global, so the
@@ -393,7 +396,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "fps": round(args.steps / dt, 3),
         "config": {"workload": f"A10 {args.scene}.xml path trace {sc.width}x{sc.height}, {sc.rpp} spp ({int(round(sc.rpp ** 0.5))}x{int(round(sc.rpp ** 0.5))} lens grid), 1 pass, "
-                               f"{args.bounces} bounces, thin lens; fused mirt_render_pass + copyToPixel"
+                               f"{args.bounces} bounces, thin lens; " + ("one fused launch that resolves its own pixels (mirt_render_first_pass, no per-ray accumulator)" if no_acu else "fused mirt_render_first_pass + copyToPixel")
                                + (f"; {world} row tiles + RCCL all_gather of RGBA8" if world > 1 else ""),
                    "width": sc.width, "height": sc.height, "rays_per_pixel": sc.rpp, "bounces": args.bounces,
                    "parallelism": f"rows/{world}", "workload_key": workload_key},
