@@ -11,7 +11,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fP
 subprocess.run(cmd, cwd=here, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 lines = open("/tmp/isa_blocks.s").read().splitlines()
 start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN2pt11" + want + r"\w*:", l))
-end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (a kernel has several s_endpgm: its early returns)
 body = lines[start:end + 1]
 blocks, cur = [], {"label": "entry", "depth": 0, "ins": [], "line": 0}
 for n, l in enumerate(body):
