@@ -576,6 +576,25 @@ napi_value Gather(napi_env env, napi_callback_info info) {
     return undef(env);
 }
 
+// mirt_abi_version / mirt_group_peer_access / mirt_gather_route: what a first run on N real devices is diagnosed from
+napi_value AbiVersion(napi_env env, napi_callback_info) { return mk_num(env, mirt_abi_version()); }
+napi_value GroupPeerAccess(napi_env env, napi_callback_info info) {
+    ARGS(3);
+    void* g; uint32_t i, j;
+    if (!get_ext(env, argv[0], &g) || !get_u32(env, argv[1], &i) || !get_u32(env, argv[2], &j)) return throw_type(env, "groupPeerAccess(group, i, j)");
+    int rc = mirt_group_peer_access((const mirt_group*)g, (int)i, (int)j);
+    if (rc < 0) return throw_mirt(env, rc, nullptr);
+    return mk_num(env, rc);
+}
+napi_value GatherRoute(napi_env env, napi_callback_info info) {
+    ARGS(2);
+    void* g; uint32_t t;
+    if (!get_ext(env, argv[0], &g) || !get_u32(env, argv[1], &t)) return throw_type(env, "gatherRoute(group, tile)");
+    int rc = mirt_gather_route((const mirt_group*)g, (int)t);
+    if (rc < 0) return throw_mirt(env, rc, nullptr);
+    return mk_num(env, rc);
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"deviceCount", DeviceCount}, {"deviceName", DeviceName}, {"version", Version},
@@ -587,6 +606,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"gridGatherSpheres", GridGatherSpheres}, {"gridGatherU32", GridGatherU32}, {"seedFill", SeedFill}, {"zero", Zero}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
         {"captureBegin", CaptureBegin}, {"captureEnd", CaptureEnd}, {"graphLaunch", GraphLaunch}, {"graphRelease", GraphRelease},
         {"groupCreate", GroupCreate}, {"groupCtx", GroupCtx}, {"groupDestroy", GroupDestroy}, {"groupFinish", GroupFinish}, {"tileRows", TileRows}, {"gather", Gather}, {"meshIngest", MeshIngest},
+        {"abiVersion", AbiVersion}, {"groupPeerAccess", GroupPeerAccess}, {"gatherRoute", GatherRoute},
     };
     for (auto& f : fns) {
         napi_value fn;

@@ -48,6 +48,7 @@ if (cmd === "pack") {
   writeFrame(out, res.pixel, w, h);
   fs.writeFileSync(out + ".radiance.f32", Buffer.from(res.radiance.buffer, res.radiance.byteOffset, res.radiance.byteLength));
   process.stderr.write(`rendered ${file} ${w}x${h} rpp ${rpp}, ${passes} pass(es), ${opt.granular ? (opt.fusion ? "kernel-by-kernel, passes fused by the runtime" : "kernel-by-kernel") : "fused"}: ${res.ms.toFixed(2)} ms on ${res.device}; passes the runtime fused from enqueues: ${res.fusedPasses}\n`);
+  if (res.routes) process.stderr.write(`gather routes per tile: ${res.routes.join(" ")}; peer access root<-tile: ${res.peerAccess.join(" ")}\n`);
 } else if (cmd === "pack-frame" || cmd === "frame") {
   if (rest.length < 4) usage();
   const frame = require("./frame.js");

@@ -326,11 +326,13 @@ function renderTiled(packed, nDevices, passes, opt) {
   group.gather(dummy.map((t) => t.radiance), dummy.map((t) => t.npix * 16), rad, 0, opt.forceRccl);
   group.finish();
   const ms = q0.timerStopMs();
+  // what the gather did: the route of every tile and whether each context reads the root's device directly (mirt.h MIRT_ROUTE_*)
+  const routes = group.routes(), peers = tiles.map((_, i) => group.peerAccess(0, i));
   const pixel = new Uint8ClampedArray(npix * 4), radiance = new Float32Array(npix * 4);
   q0.enqueueReadBuffer(frame, true, 0, pixel.length, pixel, []);
   q0.enqueueReadBuffer(rad, true, 0, radiance.byteLength, radiance, []);
   q0.finish();
-  const res = { pixel: pixel, radiance: radiance, ms: ms, device: live.length + " x " + live[0].device.getInfo(webcl.DEVICE_NAME), tiles: tiles.map((t) => (t ? [t.row0, t.nrows] : [0, 0])) };
+  const res = { pixel: pixel, radiance: radiance, ms: ms, device: live.length + " x " + live[0].device.getInfo(webcl.DEVICE_NAME), tiles: tiles.map((t) => (t ? [t.row0, t.nrows] : [0, 0])), routes: routes, peerAccess: peers };
   live.forEach((t) => t.release());
   group.release();
   return res;

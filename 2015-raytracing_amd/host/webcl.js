@@ -29,6 +29,8 @@ function native() {
     } catch (e) {
       throw new Error("mirt.node is not built (python -c 'import __graft_entry__ as g; g.build()'): " + e.message);
     }
+    // include/mirt.h MIRT_ABI_VERSION this host was written against: an addon over an older libmirt.so would pass shifted arguments
+    if (addon.abiVersion() !== 4) { const v = addon.abiVersion(); addon = null; throw new Error("libmirt.so speaks ABI " + v + ", this host 4: rebuild both"); }
   }
   return addon;
 }
@@ -284,6 +286,10 @@ class WebCLDeviceGroup {
   gather(tiles, tileBytes, out, root, transport) {
     wrap(() => native().gather(this.h, tiles.map((b) => b.h), tileBytes, out.h, root || 0, transport === true ? 1 : (transport | 0)));
   }
+  // 1 when contexts[i]'s device reads contexts[j]'s memory directly (peer access enabled at creation), 0 when copies between them are staged
+  peerAccess(i, j) { return wrap(() => native().groupPeerAccess(this.h, i, j)); }
+  // how the last gather() moved each tile: "none" | "rccl" | "peer" | "staged" | "local" (mirt.h MIRT_ROUTE_*)
+  routes() { return this.devices.map((_, t) => ["none", "rccl", "peer", "staged", "local"][wrap(() => native().gatherRoute(this.h, t))]); }
   finish() { wrap(() => native().groupFinish(this.h)); }
   release() { if (this.h) { wrap(() => native().groupDestroy(this.h)); this.h = null; this.contexts.forEach((c) => { c.h = null; }); } }
 }

@@ -212,7 +212,10 @@ def test_node_device_group_render(tmp_path, flags):
     communicator (ncclSend / ncclRecv to self): the frame must equal the compiled reference's."""
     fx, sc = load_fixture("own_gems_48x36_r4")
     out = str(tmp_path / "frame.rgba")
-    run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "gems.xml"), "48", "36", "4", "1", out, *flags)
+    log = run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "gems.xml"), "48", "36", "4", "1", out, *flags, stderr=True)
+    # the host reports how the gather moved the tile (mirt_gather_route through the addon): a device-local copy, or ncclSend/ncclRecv when forced
+    assert ("gather routes per tile: rccl;" if "--force-rccl" in flags else "gather routes per tile: local;") in log, log
+    assert "peer access root<-tile: 1" in log
     assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), fx["pixel"])
     assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(fx["radiance"]))
 
@@ -226,8 +229,10 @@ def test_node_device_group_render_n_tiles(tmp_path, flags):
     the device itself (buffers do not cross contexts; the loader's context is released when the tiles are built)."""
     fx, sc = load_fixture("own_gems_48x36_r4")
     out = str(tmp_path / "frame.rgba")
-    run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "gems.xml"), "48", "36", "4", "1", out, *flags,
-             env=dict(os.environ, MIRT_GROUP_ALLOW_REPEATED_DEVICES="1"))
+    log = run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "gems.xml"), "48", "36", "4", "1", out, *flags,
+                   env=dict(os.environ, MIRT_GROUP_ALLOW_REPEATED_DEVICES="1"), stderr=True)
+    n = int(flags[1])
+    assert "gather routes per tile: " + " ".join(["local"] * n) + ";" in log, log   # every context shares device 0 in this rehearsal
     assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), fx["pixel"])
     assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(fx["radiance"]))
 
