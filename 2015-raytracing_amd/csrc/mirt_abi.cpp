@@ -1382,18 +1382,25 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     const bool resolve_in_pass = ctx->inpass_resolve && pt::fused_resolves(d->rays_per_pixel, fresh, d->pixel || d->radiance);
     if (!d->acu && !resolve_in_pass)
         return fail(ctx, MIRT_E_ARG, "mirt_render_pass: acu may only be null for a frame's first pass (mirt_render_first_pass) with a pixel or radiance buffer and "
-                                     "rays_per_pixel dividing 256 (here: %s, %u rays per pixel%s)", fresh ? "first pass" : "NOT a first pass", d->rays_per_pixel,
-                    d->pixel || d->radiance ? "" : ", no output buffer");
+                                     "rays_per_pixel dividing 256 or 256 times a power of two up to 32 (here: %s, %u rays per pixel%s)", fresh ? "first pass" : "NOT a first pass",
+                    d->rays_per_pixel, d->pixel || d->radiance ? "" : ", no output buffer");
     if (d->acu && (rc = need(ctx, "acu", d->acu, nrays * kAcuBytes))) return rc;
     A.seeds = (int32_t*)d->seeds->ptr;
     A.acu = d->acu ? d->acu->ptr : nullptr;
     if (d->pixel && (rc = need(ctx, "pixel", d->pixel, npix * 4))) return rc;
     if (d->radiance && (rc = need(ctx, "radiance", d->radiance, npix * 16))) return rc;
+    A.chunks = 1u;
+    A.chunk_bits = ~0u;
     if (resolve_in_pass) {
         A.resolve = 1u;
         A.pixel = d->pixel ? d->pixel->ptr : nullptr;
         A.radiance = d->radiance ? d->radiance->ptr : nullptr;
         A.res_m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
+        A.chunks = pt::fused_chunks(d->rays_per_pixel);
+        if (A.chunks > 1u && !A.radiance) {   // a pixel of more than 256 rays: its sums travel from launch to launch through memory (FusedArgs::chunks)
+            if ((rc = ensure_scratch(ctx, (size_t)npix * 16))) return rc;
+            A.radiance = ctx->scratch;
+        }
     }
 
     if (A.rpp == 1) {
@@ -1422,12 +1429,28 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
         if (ctx->capturing) ctx->cap_defer = true;
         uint32_t* mask = (uint32_t*)ctx->defer + 4;
         HIPCHK(ctx, hipMemsetAsync(ctx->defer, 0, need_bytes, ctx->stream));
-        pt::launch_fused(ctx->stream, A, true, mask, nullptr, 0);
-        pt::launch_fused(ctx->stream, A, false, nullptr, mask, words);
+        // one pair of launches -- or, a pixel of more than 256 rays resolved in the pass, one pair per block of 256 rays of a pixel, in ray order: launch c
+        // goes on from the sums launch c - 1 and its redo left (FusedArgs::chunks).  The mask collects the deferred blocks of every launch.
+        void* const pixel_out = A.pixel;
+        for (uint32_t c = 0; c < A.chunks; ++c) {
+            A.chunk = c;
+            if (A.chunks > 1u) {   // every chunks-th bit from bit c on (chunks divides 32: a block's bit sits at its number modulo 32)
+                A.chunk_bits = 0u;
+                for (uint32_t b = c; b < 32u; b += A.chunks) A.chunk_bits |= 1u << b;
+            }
+            A.pixel = c + 1u == A.chunks ? pixel_out : nullptr;
+            pt::launch_fused(ctx->stream, A, true, mask, nullptr, 0);
+            pt::launch_fused(ctx->stream, A, false, nullptr, mask, words);
+        }
         ctx->defer_words = words;
         ctx->defer_unit = resolve_in_pass ? 256u : 1u;
     } else {
-        pt::launch_fused(ctx->stream, A, false, nullptr, nullptr, 0);
+        void* const pixel_out = A.pixel;
+        for (uint32_t c = 0; c < A.chunks; ++c) {
+            A.chunk = c;
+            A.pixel = c + 1u == A.chunks ? pixel_out : nullptr;
+            pt::launch_fused(ctx->stream, A, false, nullptr, nullptr, 0);
+        }
         ctx->defer_words = 0;
     }
     if (ctx->profiling && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->pe[1], ctx->stream));

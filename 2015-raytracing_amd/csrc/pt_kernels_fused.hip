@@ -443,8 +443,11 @@ PT_DEV Ray primary_ray(const FusedArgs& A, uint32_t lid) {
 #ifndef PT_RESOLVE_PRIO
 #define PT_RESOLVE_PRIO 1
 #endif
+// The block of 256 consecutive ray ids a workgroup renders (outside the redo loop): its own number -- or, a pixel of more than 256 rays being resolved
+// in `chunks` launches, block `chunk` of pixel blockIdx.x (FusedArgs::chunks).  Scalar arithmetic on kernel arguments, re-derived where it is used.
+PT_DEV uint32_t wg_block(const FusedArgs& A) { return blockIdx.x * A.chunks + A.chunk; }
 PT_DEV void resolve_block(const FusedArgs& A, const float* rows, uint64_t first, uint64_t n_local) {
-    const uint32_t rpp = A.rpp, ppb = 256u / rpp;
+    const uint32_t rpp = A.rpp, per = rpp < 256u ? rpp : 256u, ppb = 256u / per;   // per: the rays of ONE pixel this block holds (rpp > 256: FusedArgs::chunks)
     const uint32_t pix0 = (uint32_t)(first / rpp), npix = (uint32_t)(n_local / rpp);
 #if PT_RESOLVE_PRIO
     // The sums are chains of dependent additions (256 long at 256 rays per pixel, on four lanes) at the very end of a block whose other waves
@@ -454,13 +457,15 @@ PT_DEV void resolve_block(const FusedArgs& A, const float* rows, uint64_t first,
 #endif
     for (uint32_t q = threadIdx.x; q < 4u * ppb; q += 256u) {   // whole quads: 4 ppb is a multiple of 4, and so is every q - threadIdx.x
         const uint32_t j = q >> 2, c = q & 3u;
-        const float* r = rows + c * 256u + j * rpp;
+        const float* r = rows + c * 256u + j * per;
         float s = 0.0f;
-        if (rpp >= 4u) {
-            const float4* r4 = (const float4*)r;   // 16-byte aligned: the rows are, and rpp is a multiple of 4
-            for (uint32_t i = 0; i < rpp / 4u; ++i) { const float4 v = r4[i]; s += v.x; s += v.y; s += v.z; s += v.w; }
+        // a later block of a pixel of more than 256 rays: the chain goes on from the sum over the blocks before it (FusedArgs::chunks)
+        if (A.chunk != 0u && pix0 + j < npix) s = ((const float*)A.radiance)[4u * (size_t)(pix0 + j) + c];
+        if (per >= 4u) {
+            const float4* r4 = (const float4*)r;   // 16-byte aligned: the rows are, and `per` is a multiple of 4
+            for (uint32_t i = 0; i < per / 4u; ++i) { const float4 v = r4[i]; s += v.x; s += v.y; s += v.z; s += v.w; }
         } else {
-            for (uint32_t i = 0; i < rpp; ++i) s += r[i];
+            for (uint32_t i = 0; i < per; ++i) s += r[i];
         }
         const int si = (int)__float_as_uint(s);
         const float x = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp(si, 0x00, 0xf, 0xf, true));   // quad_perm [0,0,0,0]
@@ -522,12 +527,12 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
     // over when one of its samples left the guard windows (a bit per block in `defer_mask`; nothing of the block is written), and the exact
     // kernel's redo mode is one block per 32-block word of that mask, every thread one sample of each marked block in turn.  Every thread stays
     // in to the block's barrier: a lane past the end of the tile rides along as in the grid kernels.
-    uint64_t base = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // (every launch of this kernel uses 256-thread blocks: launch_fused)
+    uint64_t base = (uint64_t)wg_block(A) * 256u + threadIdx.x;   // (every launch of this kernel uses 256-thread blocks: launch_fused)
     uint32_t todo = 1u;
     uint32_t stride = 1u;
     if (!FAST && redo_mask) {
         if (A.resolve) {
-            todo = redo_mask[blockIdx.x];   // (the grid is one block per word)
+            todo = redo_mask[blockIdx.x] & A.chunk_bits;   // (the grid is one block per word; the bits of this launch's blocks: FusedArgs::chunks)
             base = (uint64_t)blockIdx.x * (32u * 256u) + threadIdx.x;
             stride = 256u;
         } else {
@@ -611,7 +616,7 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
         // keeping it (and the 64-bit addresses made from it) alive across the whole path cost spilled registers in every variant
         uint32_t t = threadIdx.x;
         asm volatile("" : "+v"(t));
-        const uint64_t again = (uint64_t)blockIdx.x * 256u + t;
+        const uint64_t again = (uint64_t)wg_block(A) * 256u + t;
         lid = (uint32_t)again;
         if (GRIDS || A.resolve) valid = again < n_local;   // (a lane past the end of the tile rode along on the tile's last sample)
     }
@@ -623,7 +628,7 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
         if (FAST && defer) pt_blk_defer[0] = 1u;
         __syncthreads();   // every lane's accumulator is final in LDS, and so is the flag
         if (FAST && pt_blk_defer[0] != 0u) {   // the whole block goes to the exact kernel: its seeds stay as they were, no pixel of it is written
-            if (threadIdx.x == 0u) atomicOr(&defer_mask[blockIdx.x >> 5], 1u << (blockIdx.x & 31u));
+            if (threadIdx.x == 0u) atomicOr(&defer_mask[wg_block(A) >> 5], 1u << (wg_block(A) & 31u));
             return;
         }
         if (valid) {
@@ -631,8 +636,8 @@ __global__ void __launch_bounds__(256, WAVES ? WAVES : (GRIDS ? PT_FUSED_WAVES_G
             if (A.acu) ((float4*)A.acu)[lid] = make_float4(park_mem[0][threadIdx.x], park_mem[1][threadIdx.x], park_mem[2][threadIdx.x], park_mem[3][threadIdx.x]);
         }
         // the block's first ray id: wave-uniform (blockIdx alone in the optimistic kernel; the marked block of this trip in the redo loop)
-        const uint64_t first = FAST ? (uint64_t)blockIdx.x * 256u
-                                    : (uint64_t)blockIdx.x * (stride == 256u ? 32u * 256u : 256u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctz(todo)) * stride;
+        const uint64_t first = FAST || stride != 256u ? (uint64_t)wg_block(A) * 256u
+                                                      : (uint64_t)blockIdx.x * (32u * 256u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctz(todo)) * 256u;
         resolve_block(A, &park_mem[0][0], first, n_local);
         if (FAST) return;
         __syncthreads();   // the redo loop's next block parks into the same rows
@@ -696,7 +701,8 @@ void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_
 
     }
     // redo mode: one thread per 32-sample word of the mask, or (in-pass resolve: the mask is per block) one block per 32-block word
-    const dim3 grid(redo_mask && a.resolve ? (unsigned)redo_words : (unsigned)((n + 255) / 256));
+    // (resolving a pixel of more than 256 rays: one workgroup per pixel and launch, FusedArgs::chunks -- n is a multiple of 256 * chunks then)
+    const dim3 grid(redo_mask && a.resolve ? (unsigned)redo_words : (unsigned)((n + 255) / 256 / (a.chunks ? a.chunks : 1u)));
     // dynamic LDS: the waves' exchange areas, then the staged tables (what the scene needs, not the 16 KB cap: occupancy), then the staged triangles
     const size_t lds_tri = tri_words ? (size_t)(tri_base4 - tri_base + tri_words) * 4u : 0u;
     const size_t lds2 = (size_t)kCoopWordsPerBlock * 4u + lds_tri, lds = (size_t)kCoopWordsPerBlock * 4u + (staged ? (size_t)used * 4u : 0u) + lds_tri;

@@ -97,9 +97,23 @@ struct FusedArgs {
     void* radiance;          // float4[nrows*width] or null
     float res_m;             // 1 / (rpp * passes), A10 code.js:1412
     uint32_t resolve;
+    // A pixel of MORE than 256 rays (rpp = 256 * chunks; chunks a power of two <= 32: 1024 rays are 4) resolves in `chunks` launches: launch c renders the
+    // c-th block of 256 ray ids of EVERY pixel (workgroup b: block b * chunks + c) and continues the pixel's chain of additions from what `radiance`
+    // holds -- the sums over the blocks before it, written by launches 0 .. c-1 -- so the reference's one chain (A10 code.cl:1377-1380) is cut at
+    // multiples of 256 and carried through memory, 16 B per pixel and launch instead of 16 B per ray.  `pixel` is given to the last launch only.
+    uint32_t chunks;         // 1, or rpp / 256
+    uint32_t chunk;          // this launch's c
+    uint32_t chunk_bits;     // redo mode: the bits of a 32-block mask word that are blocks of this launch (all ones when chunks == 1)
 };
-// whether a pass with these arguments resolves inside the kernel: first pass of a frame, whole pixels per block, somewhere to put the result
-inline bool fused_resolves(uint32_t rpp, bool fresh, bool want_out) { return fresh && want_out && rpp <= 256u && 256u % rpp == 0u; }
+// whether a pass with these arguments resolves inside the kernel: first pass of a frame, whole pixels per block (or whole blocks per pixel, see
+// FusedArgs::chunks), somewhere to put the result
+inline uint32_t fused_chunks(uint32_t rpp) { return rpp > 256u ? rpp / 256u : 1u; }
+inline bool fused_resolves(uint32_t rpp, bool fresh, bool want_out) {
+    if (!fresh || !want_out || rpp == 0u) return false;
+    if (rpp <= 256u) return 256u % rpp == 0u;
+    const uint32_t c = rpp / 256u;
+    return rpp % 256u == 0u && c <= 32u && (c & (c - 1u)) == 0u;
+}
 // fast: the optimistic kernel (writes deferred samples' bits into defer_mask); !fast: the exact kernel over `list` (or everything)
 void launch_fused(hipStream_t s, const FusedArgs& a, bool fast, uint32_t* defer_mask, const uint32_t* redo_mask, uint32_t redo_words);
 bool fused_fast_available();   // compiled with PT_EXACT_FAST_DIV

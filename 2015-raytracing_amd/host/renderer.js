@@ -270,7 +270,7 @@ class FusedRenderer {
     if (opt.seeds) this.q.enqueueWriteBuffer(this.seeds, false, 0, this.nrays * 4, opt.seeds.subarray(first, first + this.nrays), []);
     else this.q.seedFill(this.seeds, first, this.nrays, opt.seedBase || 0);
     // not zeroed: the first pass initialises it (firstPass below).  opt.keepAcu === false: a one-pass frame without the 16 bytes per ray -- the pass
-    // resolves its pixels itself (mirt_render_first_pass with acu == NULL: rays_per_pixel must divide 256, and there is no second pass)
+    // resolves its pixels itself (mirt_render_first_pass with acu == NULL: rays_per_pixel must divide 256 or be 256 times a power of two up to 32, and there is no second pass)
     this.acu = opt.keepAcu === false ? null : this.ctx.createBuffer(webcl.MEM_READ_WRITE, this.nrays * 16);
     this.pixel = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, this.npix * 4);
     this.radiance = this.ctx.createBuffer(webcl.MEM_WRITE_ONLY, this.npix * 16);

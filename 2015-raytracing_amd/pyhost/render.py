@@ -202,7 +202,8 @@ class FusedRenderer:
         """nrows None: the whole image from row0 = 0.  nrows == 0 is an EMPTY tile (more ranks than rows): it owns minimal buffers and
         its passes do nothing -- it is not the whole frame.
         keep_acu False: no per-ray accumulator at all (16 B per ray never allocated); only a frame's first pass can then run, with
-        rays_per_pixel dividing 256: the pass resolves its pixels itself (mirt_render_first_pass with acu == NULL)."""
+        rays_per_pixel dividing 256, or 256 times a power of two up to 32 (1024, 4096): the pass resolves its pixels itself
+        (mirt_render_first_pass with acu == NULL)."""
         self.ctx, self.s = ctx, scene
         self.dev = mirt.DeviceScene(ctx, scene)
         self.row0 = row0

@@ -55,6 +55,14 @@ PEAK_HBM_GBS = 8000.0
 SIMDS, NOMINAL_HZ, MEASURED_ISSUE_CYCLES = 1024, 2.4e9, 2.4   # profiles/micro/valu_rate.hip: cycles per plain fp32 VOP2 wave-instruction at 8 waves (spec: 2)
 
 
+def resolves_in_pass(rpp):
+    """ray counts at which a frame's first pass resolves its own pixels (include/mirt.h mirt_render_first_pass): divisors of 256, or 256 times a power of two up to 32"""
+    if rpp <= 256:
+        return 256 % rpp == 0
+    c = rpp // 256
+    return rpp % 256 == 0 and c <= 32 and c & (c - 1) == 0
+
+
 def csrc_sha256():
     """Hash of the kernel sources this libmirt.so is built from: the stamp that ties a rocprofv3 PMC summary to a build."""
     import glob
@@ -310,7 +318,7 @@ def main():
     ctx.set_profiling(True)
     if os.environ.get("MIRT_EXACT_ONLY") == "1":   # A/B knob: the single exact kernel instead of the default optimistic pair
         ctx.set_exact_only(True)
-    no_acu = not (args.keep_acu or os.environ.get("BENCH_KEEP_ACU") == "1") and 256 % sc.rpp == 0 and os.environ.get("MIRT_INPASS_RESOLVE", "1") != "0"
+    no_acu = not (args.keep_acu or os.environ.get("BENCH_KEEP_ACU") == "1") and resolves_in_pass(sc.rpp) and os.environ.get("MIRT_INPASS_RESOLVE", "1") != "0"
     fr = render.FusedRenderer(ctx, sc, row0=row0, nrows=nrows, want_radiance=True, keep_acu=not no_acu)
     # the RGBA8 tile lives in a torch tensor so RCCL can move it
     tile = torch.zeros(max_rows * sc.width * 4, dtype=torch.uint8, device="cuda")

@@ -189,7 +189,12 @@ MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
  * Then, and only then, `acu` may be NULL: nothing per ray but the seed touches memory (8 B per sample + 20 B per pixel) and the
  * 16 bytes per ray are never allocated; with `acu` given it is written as before (what a second progressive pass needs).  Results
  * are bit-identical either way.  In this mode the optimistic / exact kernel pair hands over whole blocks of 256 samples
- * (mirt_pass_deferred counts them as such).  MIRT_INPASS_RESOLVE=0 in the environment keeps the separate copyToPixel. */
+ * (mirt_pass_deferred counts them as such).  MIRT_INPASS_RESOLVE=0 in the environment keeps the separate copyToPixel.
+ * MORE than 256 rays per pixel, 256 times a power of two up to 32 (the squares among them: 1024 = BASELINE config 5's 32 x 32 lens grid,
+ * and 4096): a pixel spans 4 (16) blocks, so the pass is queued as 4 (16) launches, launch c rendering the c-th block of every pixel and
+ * going on from the sums launch c - 1 left in `radiance` (or in the context's scratch buffer when the caller passes none): the
+ * reference's one chain of additions, cut at multiples of 256 and carried through memory at 16 B per pixel and launch instead of 16 B
+ * per ray.  `acu` may be NULL there too; results are bit-identical. */
 MIRT_API int mirt_render_first_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
 /* Two ways to run the pass, identical results.  Default: the optimistic pair -- a kernel whose divisions are 3-operation
  * forms proven bit-exact inside a guard window (exhaustively, on the device: profiles/r1_divcheck_exhaustive.txt), plus the

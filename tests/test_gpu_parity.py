@@ -649,12 +649,33 @@ def test_config5_one_gpus_share_at_full_size(ctx, pkg):
         fr.execute_render(bounces=8, fresh=True)
         ms8 = ctx.pass_timing()[0]
         fr.release()
+        # without the 17 GB: the pass resolves its pixels block by block of a pixel's 1024 rays (four launches, FusedArgs::chunks) -- the same frame
+        na = render.FusedRenderer(ctx, sc, row0=row0, nrows=nrows, want_radiance=False, keep_acu=False)
+        na.execute_render(bounces=5, fresh=True)
+        ms5_na = sum(ctx.pass_timing())
+        assert np.array_equal(na.pixel.read(np.uint8).reshape(nrows, sc.width, 4), pix)
+        na.release()
+        ms5_sep = None
+        if tile == 0:   # and the round-3 way, for the record: accumulators written, then read again by the separate copyToPixel
+            os.environ["MIRT_INPASS_RESOLVE"] = "0"
+            try:
+                c2 = mirt.Context(0)
+            finally:
+                del os.environ["MIRT_INPASS_RESOLVE"]
+            c2.set_profiling(True)
+            f2 = render.FusedRenderer(c2, sc, row0=row0, nrows=nrows, want_radiance=False)
+            f2.execute_render(bounces=5, fresh=True)
+            ms5_sep = sum(c2.pass_timing())
+            assert np.array_equal(f2.pixel.read(np.uint8).reshape(nrows, sc.width, 4), pix)
+            f2.release()
+            c2.destroy()
         band = render.FusedRenderer(ctx, sc, row0=row0 + 100, nrows=48, want_radiance=False)
         band.execute_render(bounces=5, fresh=True)
         assert np.array_equal(band.pixel.read(np.uint8).reshape(48, sc.width, 4), pix[100:148])
         band.release()
         assert pix[..., :3].max() > 0
         report[f"tile{tile}"] = {"row0": row0, "nrows": nrows, "samples": 3840 * 270 * 1024, "ms_5_bounces": round(ms5, 2), "ms_8_bounces": round(ms8, 2),
+                                 "ms_5_bounces_no_acu_pass_plus_resolve": round(ms5_na, 2), "ms_5_bounces_separate_resolve_pass_plus_resolve": ms5_sep and round(ms5_sep, 2),
                                  "Msamples_s_5": round(3840 * 270 * 1024 / ms5 / 1e3, 1), "Msamples_s_8": round(3840 * 270 * 1024 / ms8 / 1e3, 1)}
     ctx.set_profiling(False)
     out = os.path.join(ROOT, "gpurun_out")

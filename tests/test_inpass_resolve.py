@@ -137,3 +137,77 @@ def test_acu_is_only_optional_where_the_pass_resolves(ctx, pkg):
     fr.execute_render(fresh=True)                       # and the context is fine afterwards
     assert np.array_equal(fr.pixel.read(np.uint8).reshape(-1, 4), fx["pixel"])
     fr.release()
+
+
+@pytest.mark.parametrize("exact_only", [False, True], ids=["optimistic", "exact_only"])
+@pytest.mark.parametrize("rpp,size", [(1024, (7, 5)), (4096, (3, 2))])
+@pytest.mark.parametrize("name", ["cornell_32x24_r4", "cornell_teapot3_32x24_r4", "own_flat_32x24_r4"])
+def test_pixels_of_more_than_256_rays_resolve_block_by_block(ctx, pkg, name, rpp, size, exact_only):
+    """BASELINE config 5's ray count (1024 = a 32 x 32 lens grid: four blocks of 256 ray ids per pixel) and the next square that is 256 times a
+    power of two (4096: sixteen): the pass runs once per block of a pixel, in ray order, each launch going on from the sums the one before left
+    (pt_launch.hpp FusedArgs::chunks) -- the reference's single chain of additions (A10 code.cl:1377-1380), cut at multiples of 256.  Against the
+    separate copyToPixel of the same library over a kept accumulator (bit for bit: frame, radiance, seeds), with and without a radiance buffer of
+    the caller's, on a scene with grid meshes, on one that defers blocks to the exact kernel (own_flat), and -- 1024 rays -- against the CPU oracle."""
+    from raytracing_amd.pyhost import render, scene
+    fx, sc0 = load_fixture(name)
+    w, h = size
+    d = dict(sc0.d)
+    ps = scene.PackedScene(d).resized(w, h, rpp)
+    sc = A.Scene(ps.d)
+    seeds = A.make_seeds(sc.total_rays, seed_base=rpp + w)
+    ctx.set_exact_only(exact_only)
+    try:
+        b = render.FusedRenderer(ctx, ps, seeds=seeds)
+        b.execute_render(fresh=False)                                   # accumulator + the separate copyToPixel
+        deferred_samples = ctx.pass_deferred()
+        for want_radiance in (True, False):
+            a = render.FusedRenderer(ctx, ps, seeds=seeds, keep_acu=False, want_radiance=want_radiance)
+            a.pixel.write(np.full(sc.width * sc.height * 4, 7, np.uint8))
+            a.execute_render(fresh=True)
+            deferred_blocks = ctx.pass_deferred()
+            assert np.array_equal(a.pixel.read(np.uint8), b.pixel.read(np.uint8)), (rpp, want_radiance)
+            if want_radiance:
+                assert np.array_equal(bits(a.radiance.read(np.float32)), bits(b.radiance.read(np.float32))), rpp
+            assert np.array_equal(a.seeds.read(np.int32), b.seeds.read(np.int32)), rpp
+            assert deferred_blocks % 256 == 0 and deferred_samples <= deferred_blocks <= 256 * deferred_samples
+            a.release()
+        # and with the accumulator kept beside the in-pass resolve: every per-ray value too
+        a = render.FusedRenderer(ctx, ps, seeds=seeds, keep_acu=True)
+        a.acu.write(np.full(sc.total_rays * 4, np.nan, np.float32))
+        a.execute_render(fresh=True)
+        assert np.array_equal(bits(a.acu.read(np.float32)), bits(b.acu.read(np.float32)))
+        assert np.array_equal(a.pixel.read(np.uint8), b.pixel.read(np.uint8))
+        a.release()
+        if name == "own_flat_32x24_r4" and not exact_only:
+            assert deferred_samples > 0, "own_flat no longer defers: the redo launches between the chunks are not exercised"
+        if rpp == 1024 and not exact_only:
+            st = A.PassState(sc, seeds)
+            A.run_pass(A.load_oracle(), sc, st)
+            assert np.array_equal(b.pixel.read(np.uint8).reshape(-1, 4), st.pixel)
+        b.release()
+    finally:
+        ctx.set_exact_only(False)
+
+
+def test_row_tiles_of_pixels_of_1024_rays(ctx, pkg):
+    """a row tile of the block-by-block resolve: its pixels are the whole frame's, nothing is written past them"""
+    from raytracing_amd.pyhost import render, scene
+    fx, sc0 = load_fixture("cornell_teapot3_32x24_r4")
+    ps = scene.PackedScene(dict(sc0.d)).resized(5, 6, 1024)
+    sc = A.Scene(ps.d)
+    seeds = A.make_seeds(sc.total_rays, seed_base=99)
+    whole = render.FusedRenderer(ctx, ps, seeds=seeds)
+    whole.execute_render(fresh=False)
+    want = whole.pixel.read(np.uint8).reshape(-1, 4)
+    for row0, nrows in [(0, 1), (2, 3), (5, 1)]:
+        fr = render.FusedRenderer(ctx, ps, seeds=seeds, row0=row0, nrows=nrows, keep_acu=False)
+        guard = np.full(nrows * 5 * 4 + 64, 0xAB, np.uint8)
+        fr.pixel.release()
+        fr.pixel = ctx.buffer(guard.size)
+        fr.pixel.write(guard)
+        fr.execute_render(fresh=True)
+        got = fr.pixel.read(np.uint8)
+        assert np.array_equal(got[:nrows * 5 * 4].reshape(-1, 4), want[row0 * 5:(row0 + nrows) * 5]), (row0, nrows)
+        assert np.all(got[nrows * 5 * 4:] == 0xAB)
+        fr.release()
+    whole.release()
