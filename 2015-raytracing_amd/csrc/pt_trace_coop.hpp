@@ -37,6 +37,9 @@
 #pragma once
 #include "pt_trace.hpp"
 
+#ifndef PT_COOP_STEP_ASM
+#define PT_COOP_STEP_ASM 1   // phase A's stepping loop with its control flow written out (0: the same loop left to the compiler; PT_COUNT builds and tables in memory use that one)
+#endif
 #ifndef PT_COOP_REMAT
 #define PT_COOP_REMAT 1
 #endif
@@ -134,10 +137,14 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
     const uint32_t zs = S.n * S.n, ys = S.n;   // n <= 1024 (check_grid): 24-bit multiplies are exact
     const uint32_t last = S.n - 1u;
     uint32_t cell = 0u, pk = 0u;
+    uint32_t scx = 0u, scy = 0u, scz = 0u;   // what a step along x / y / z adds to the cell index: +-1, +-n, +-n^2
     const bool fwx = ray.d.x >= 0, fwy = ray.d.y >= 0, fwz = ray.d.z >= 0;   // code.cl:701-705: d >= 0 ? +1, n : -1, -1
     float cmin = 0.0f, cmax = 0.0f;
     uint32_t i = 0u, end = 0u;
     bool alive = want && !(bh.tmin >= ray.maxt);
+    // where the walk ends at the latest: the ray's way out of the set's box, or its own end (t >= tmax || t >= maxt is t >= the smaller of the two:
+    // v_min_f32 passes the other operand when one is a NaN, and a comparison with a NaN is false either way)
+    const float tend = cl_min(bh.tmax, ray.maxt);
     if (want) {
         bool dfr = FAST && S.walk_ok == 0u;
         const Axis ax = axis_setup_t<FAST>(ray.o.x, ray.d.x, bh.tmin, S.bound[0], S.bound[4], S.n, S.delta[0], S.rdelta[0], rr.x, dfr);
@@ -148,9 +155,12 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
         dtx = ax.dt; dty = ay.dt; dtz = az.dt;
         cmin = bh.tmin;
         cmax = cl_min(cl_min(tnx, tny), tnz);
-        // the slab indices packed ten bits each (0 <= slab < n <= 1024 while the ray is inside) and the cell index carried along
+        // the cell index is carried along
         cell = __umul24((uint32_t)az.slab, zs) + __umul24((uint32_t)ay.slab, ys) + (uint32_t)ax.slab;
-        pk = (uint32_t)ax.slab | (uint32_t)ay.slab << 10 | (uint32_t)az.slab << 20;
+        // pk: the steps LEFT on each axis before the ray leaves the grid, ten bits each (0 <= slab < n <= 1024 while the ray is inside): "the step leaves
+        // the grid" (code.cl:701-705's limit, n or -1) is "the slab stepped FROM is n - 1 or 0" is "the stepped axis' field is 0"
+        pk = (fwx ? last - (uint32_t)ax.slab : (uint32_t)ax.slab) | (fwy ? last - (uint32_t)ay.slab : (uint32_t)ay.slab) << 10 | (fwz ? last - (uint32_t)az.slab : (uint32_t)az.slab) << 20;
+        scx = fwx ? 1u : ~0u; scy = fwy ? ys : 0u - ys; scz = fwz ? zs : 0u - zs;
         range(cell, i, end);
     }
     keys[lane] = kNone;
@@ -166,39 +176,121 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
         if (lane == 0u) *pool_count = 0u;
         wave_fence();
         pt_count(PC_GRID_PHASES + PCK);
-        // ---- phase A: the lane's whole way through the grid (code.cl:1028-1066's step, unchanged), one record per cell with a list.
+        // ---- phase A: the lane's whole way through the grid (code.cl:1028-1066's step), one record per cell with a list.
+        // The step as selects, on a packing made for it: the stepped axis' steps-left field is one variable-offset v_bfe_u32 and its update always a
+        // subtraction, the cell index moves by a per-lane constant.  Measured (cornell_teapot3 / cornell_teapot / own_gems 1080p x 16, ms per pass,
+        // profiles/r4_ab.tsv): the reference's if / else-if / else with slab indices 24.2 / 16.8 / 11.5; this, compiled, 23.6 / 16.1 / 10.9; this with
+        // the loop's control flow written out (below) 21.0 / 14.5 / 10.4.
         // Measured and not kept: the walk's state kept out of phase B by walking the way again after a full pool (no spill
         // in the 96-register build, 5 % slower: pools do fill); record slots handed out by a ballot instead of the LDS atomic (bit-identical,
         // 10 % slower: the compiler's exec-mask bookkeeping for the loop grew by a quarter); "anything ahead?" bits per cell and octant that
         // end a walk with only empty cells left (-18 % lane steps, 5 % slower: one more test and register in this loop).
-        while (alive) {
-            pt_count(PC_GRID_A_STEPS + PCK); pt_count(PC_GRID_A_LANE_STEPS + PCK, true);
-            if (i != end) {
-                const uint32_t slot = __hip_atomic_fetch_add(pool_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (slot >= kCoopPool) break;   // the pool is full: this cell is the first record of the lane's next sweep
-                pool[slot] = make_uint4(i, (end - i) | lane << 24, __float_as_uint(cmin), __float_as_uint(cmax));
-                i = end;
+        if (PT_COOP_STEP_ASM && !PT_COUNT && LDS_TABLES) {
+#if PT_COOP_STEP_ASM
+            if (alive) {
+            // The loop of the other branch, operation for operation, with the control flow the compiler cannot express: its structurizer spends 27
+            // scalar instructions a step on the exec masks of a loop with two exits and a rare side path (beside 23 vector instructions of
+            // work); here a step is 22 vector + 5 scalar instructions + 2 LDS reads.  exec on entry = the lanes that walk; a lane leaves by clearing
+            // its exec bit (its walk is over) or through `stall` (it found the pool full and walks on in the next sweep).
+            uint32_t flag, tb, tc, tsh;
+            unsigned long long s_save, s_stall, s_ex, s_ey, s_t;
+            const uint32_t pool_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&pt_lds_dyn[wbase + (uint32_t)CW_POOL * 64u];
+            const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&pt_lds_dyn[toff];
+            const uint32_t lane24 = lane << 24;
+            static_assert(((uint32_t)CW_COUNT - (uint32_t)CW_POOL) * 64u * 4u == 1024u, "the pool's counter sits 1024 bytes behind its first record");
+            asm volatile(
+                "s_mov_b64 %[save], exec\n\t"
+                "s_mov_b64 %[stall], 0\n"
+                ".Lcoop_top_%=:\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cmp_ne_u32_e32 vcc, %[i], %[end]\n\t"
+                "s_cbranch_vccz .Lcoop_step_%=\n\t"
+                // lanes whose cell holds primitives: a slot of the pool each, or -- pool full -- out of this sweep with the cell still theirs
+                "s_mov_b64 %[t], exec\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "v_mov_b32_e32 %[a], 1\n\t"
+                "ds_add_rtn_u32 %[a], %[pool], %[a] offset:1024\n\t"
+                "v_sub_u32_e32 %[b], %[end], %[i]\n\t"
+                "v_or_b32_e32 %[b], %[b], %[lane24]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cmp_gt_u32_e32 vcc, 64, %[a]\n\t"
+                "s_andn2_b64 %[ex], exec, vcc\n\t"
+                "s_or_b64 %[stall], %[stall], %[ex]\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "v_lshl_add_u32 %[a], %[a], 4, %[pool]\n\t"
+                "ds_write2_b32 %[a], %[i], %[b] offset1:1\n\t"
+                "ds_write2_b32 %[a], %[cmin], %[cmax] offset0:2 offset1:3\n\t"
+                "s_andn2_b64 exec, %[t], %[ex]\n\t"
+                "s_cbranch_execz .Lcoop_done_%=\n"
+                ".Lcoop_step_%=:\n\t"
+                // the step (code.cl:1028-1066): the axis whose plane the ray reached -- x before y before z -- moves on
+                "v_cmp_eq_f32_e64 %[ex], %[cmax], %[tnx]\n\t"
+                "v_cmp_eq_f32_e64 %[ey], %[cmax], %[tny]\n\t"
+                "v_add_f32_e32 %[a], %[tnx], %[dtx]\n\t"
+                "v_add_f32_e32 %[b], %[tny], %[dty]\n\t"
+                "v_add_f32_e32 %[c], %[tnz], %[dtz]\n\t"
+                "s_or_b64 %[t], %[ex], %[ey]\n\t"
+                "s_andn2_b64 %[ey], %[ey], %[ex]\n\t"
+                "v_cndmask_b32_e64 %[tnx], %[tnx], %[a], %[ex]\n\t"
+                "v_cndmask_b32_e64 %[tnz], %[c], %[tnz], %[t]\n\t"
+                "v_cndmask_b32_e64 %[tny], %[tny], %[b], %[ey]\n\t"
+                "v_cndmask_b32_e64 %[sh], 20, 10, %[ey]\n\t"
+                "v_cndmask_b32_e64 %[sh], %[sh], 0, %[ex]\n\t"
+                "v_cndmask_b32_e64 %[a], %[scz], %[scy], %[ey]\n\t"
+                "v_cndmask_b32_e64 %[a], %[a], %[scx], %[ex]\n\t"
+                "v_bfe_u32 %[b], %[pk], %[sh], 10\n\t"
+                "v_cmp_nge_f32_e32 vcc, %[cmax], %[tend]\n\t"
+                "v_cmp_ne_u32_e64 %[t], 0, %[b]\n\t"
+                "v_lshl_add_u32 %[pk], -1, %[sh], %[pk]\n\t"
+                "v_add_u32_e32 %[cell], %[cell], %[a]\n\t"
+                "s_and_b64 vcc, vcc, %[t]\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz .Lcoop_done_%=\n\t"
+                // the next cell: its window and its list
+                "v_lshl_add_u32 %[a], %[cell], 2, %[tbase]\n\t"
+                "v_mov_b32_e32 %[cmin], %[cmax]\n\t"
+                "ds_read_b32 %[i], %[a]\n\t"
+                "ds_read_b32 %[end], %[a] offset:4\n\t"
+                "v_min3_f32 %[cmax], %[tnx], %[tny], %[tnz]\n\t"
+                "s_branch .Lcoop_top_%=\n"
+                ".Lcoop_done_%=:\n\t"
+                "s_mov_b64 exec, %[save]\n\t"
+                "v_cndmask_b32_e64 %[a], 0, 1, %[stall]"
+                : [tnx] "+v"(tnx), [tny] "+v"(tny), [tnz] "+v"(tnz), [pk] "+v"(pk), [cell] "+v"(cell), [cmin] "+v"(cmin), [cmax] "+v"(cmax), [i] "+v"(i), [end] "+v"(end),
+                  [a] "=&v"(flag), [b] "=&v"(tb), [c] "=&v"(tc), [sh] "=&v"(tsh),
+                  [save] "=&s"(s_save), [stall] "=&s"(s_stall), [ex] "=&s"(s_ex), [ey] "=&s"(s_ey), [t] "=&s"(s_t)
+                : [dtx] "v"(dtx), [dty] "v"(dty), [dtz] "v"(dtz), [scx] "v"(scx), [scy] "v"(scy), [scz] "v"(scz), [tend] "v"(tend), [lane24] "v"(lane24),
+                  [pool] "v"(pool_addr), [tbase] "s"(tbase)
+                : "vcc", "scc", "memory");
+            alive = flag != 0u;
             }
-            const float t = cmax;
-            bool out;
-            // "the step leaves the grid" (code.cl:701-705's limit, n or -1) is "the slab stepped FROM is n - 1 or 0"
-            // The reference's if / else-if / else (x, then y, then z: code.cl:1028-1066): the three branches only pick the axis' values; the
-            // comparison and the updates happen once, behind them.  (Measured, cornell_teapot3 / cornell_teapot / own_gems ms per pass: every
-            // branch with its own compare and updates 25.9 / 17.9 / 11.8; all selects 25.1 / 17.1 / 11.3; this 24.7 / 17.2 / 11.7; the loop
-            // spelled without `break` is slower with either, 25.8-26.0.)
-            uint32_t fld, lim, dpk, dcell;
-            if (t == tnx) { tnx += dtx; fld = pk & 1023u; lim = fwx ? last : 0u; dpk = fwx ? 1u : ~0u; dcell = fwx ? 1u : ~0u; }
-            else if (t == tny) { tny += dty; fld = (pk >> 10) & 1023u; lim = fwy ? last : 0u; dpk = fwy ? 1u << 10 : 0u - (1u << 10); dcell = fwy ? ys : 0u - ys; }
-            else { tnz += dtz; fld = pk >> 20; lim = fwz ? last : 0u; dpk = fwz ? 1u << 20 : 0u - (1u << 20); dcell = fwz ? zs : 0u - zs; }
-            out = t >= bh.tmax || fld == lim;
-            pk += dpk;
-            cell += dcell;
-            // ... or the cell starts at or beyond the ray's end: a hit needs cmin <= t < maxt, and cmin only grows from here
-            // (the reference walks on to the grid's far side rejecting every hit; nothing it computes there survives)
-            if (out || t >= ray.maxt) { alive = false; break; }
-            cmin = t;
-            cmax = cl_min(cl_min(tnx, tny), tnz);
-            range(cell, i, end);
+#endif
+        } else {
+            bool stalled = false;   // "found the pool full": the only way a lane leaves the loop below and walks on in the next sweep
+            if (alive) for (;;) {
+                pt_count(PC_GRID_A_STEPS + PCK); pt_count(PC_GRID_A_LANE_STEPS + PCK, true);
+                if (__builtin_expect(i != end, 0)) {
+                    const uint32_t slot = __hip_atomic_fetch_add(pool_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (slot >= kCoopPool) { stalled = true; break; }   // the pool is full: this cell is the first record of the lane's next sweep
+                    pool[slot] = make_uint4(i, (end - i) | lane << 24, __float_as_uint(cmin), __float_as_uint(cmax));
+                }
+                const float t = cmax;
+                // the reference's if / else-if / else (x, then y, then z: code.cl:1028-1066)
+                const bool ex = t == tnx, ey = !ex && t == tny, ez = !ex && !ey;
+                const float vx = tnx + dtx, vy = tny + dty, vz = tnz + dtz;
+                tnx = ex ? vx : tnx; tny = ey ? vy : tny; tnz = ez ? vz : tnz;
+                const uint32_t sh = ex ? 0u : (ey ? 10u : 20u);
+                // the walk ends where the step leaves the grid, or where the next cell would start at or beyond the ray's end: a hit needs cmin <= t < maxt,
+                // and cmin only grows from here (the reference walks on to the grid's far side rejecting every hit; nothing it computes there survives)
+                const bool out = t >= tend || __builtin_amdgcn_ubfe(pk, sh, 10u) == 0u;
+                pk -= 1u << sh;
+                cell += ex ? scx : (ey ? scy : scz);
+                if (out) break;
+                cmin = t;
+                cmax = cl_min(cl_min(tnx, tny), tnz);
+                range(cell, i, end);
+            }
+            alive = stalled;
         }
         wave_fence();
         uint32_t n_rec = __builtin_amdgcn_readfirstlane(*pool_count);
