@@ -324,7 +324,7 @@ PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, co
 // axis_setup (pt_device.hpp) with the optimistic kernel's divisions: every quotient is div_exact3 on a refined reciprocal.  The
 // denominators are the ray direction (ray_guard), the slab count and the slab width; numerators and the slab width are checked
 // here, per lane, and a lane outside the windows marks its sample for the exact kernel.
-PT_DEV bool num_window(float v) { const float a = __builtin_fabsf(v); return v == 0.0f || (a >= 8.6736174e-19f && a <= 1.1529215e18f); }   // 0 | 2^-60 .. 2^60
+PT_DEV bool num_window(float v) { const float a = __builtin_fabsf(v); return (v == 0.0f) | ((a >= 8.6736174e-19f) & (a <= 1.1529215e18f)); }   // 0 | 2^-60 .. 2^60
 PT_DEV bool den_window(float v) { const float a = __builtin_fabsf(v); return a >= 9.094947e-13f && a <= 1.0995116e12f; }                    // 2^-40 .. 2^40
 // The slab width delta = (hi - lo) / n and 1 / delta depend on the set alone: the host computes them once (GridArgs::delta / rdelta,
 // correctly rounded, which is what div_exact3 / rcp_refined give inside their windows; GridArgs::walk_ok says the windows hold).
@@ -334,9 +334,10 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     Axis a;
     const float x = cl_fma(tmin, d, o);                    // code.cl:698
     const float num0 = x - lo;
-    a.slab = f2i(div_exact3(num0, delta, rdelta));
-    if (a.slab < 0) a.slab = 0;
-    if ((uint32_t)a.slab >= n) a.slab = (int)(n - 1u);
+    {   // if (slab < 0) slab = 0; if (slab >= n) slab = n - 1 (code.cl:699-700), spelled so that it is one v_med3_i32
+        const int q = f2i(div_exact3(num0, delta, rdelta)), top = (int)(n - 1u), q0 = q > 0 ? q : 0;
+        a.slab = q0 < top ? q0 : top;
+    }
     const bool fwd = d >= 0;
     a.dslab = fwd ? 1 : -1;
     a.limit = fwd ? (int)n : -1;
@@ -344,7 +345,9 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     const float xnext = cl_fma((float)(a.slab + (fwd ? 1 : 0)), delta, lo);   // code.cl:706
     const float num1 = xnext - o;
     a.tnext = div_exact3(num1, d, rd);
-    defer = defer || !(num_window(num0) && num_window(num1));
+    // (bitwise on purpose: with || and && the compiler branches around the second window of a lane that already defers -- a dozen scalar instructions
+    // and a block boundary per axis of every walk, to save six compares nobody waits for)
+    defer = defer | !(num_window(num0) & num_window(num1));
     return a;
 }
 

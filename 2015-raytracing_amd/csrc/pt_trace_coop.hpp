@@ -117,7 +117,7 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
                                     // segment loop and kept alive -- in scratch, the one register the allocator had nowhere else to put
 #endif
     const uint32_t lane = tid & 63u;
-    const uint32_t wbase = (tid >> 6) * kCoopWordsPerWave;
+    const uint32_t wbase = __umul24(tid >> 6, kCoopWordsPerWave);
 #define CW_MINE(row) pt_lds_dyn[wbase + (uint32_t)(row) * 64u + lane]
 #define CW_OF(row, l) pt_lds_dyn[wbase + (uint32_t)(row) * 64u + (l)]
     unsigned long long* const keys = (unsigned long long*)&pt_lds_dyn[wbase + (uint32_t)CW_KEY * 64u];
@@ -163,7 +163,11 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
         scx = fwx ? 1u : ~0u; scy = fwy ? ys : 0u - ys; scz = fwz ? zs : 0u - zs;
         range(cell, i, end);
     }
-    keys[lane] = kNone;
+    {   // keys[lane] = kNone, from a constant made here: hoisted out of the segment loop the pair of all-ones registers was kept in scratch and re-loaded per walk
+        uint32_t ones = ~0u;
+        asm volatile("" : "+v"(ones));
+        keys[lane] = (unsigned long long)ones << 32 | ones;
+    }
     // one past the last slot of the set: a (ray, primitive) pair is only ever formed below it (a table that lies cannot send a load astray)
     uint32_t nslots = S.nslots;
     if (nslots == 0u) {
