@@ -194,10 +194,12 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
             if (alive) {
             // The loop of the other branch, operation for operation, with the control flow the compiler cannot express: its structurizer spends 27
             // scalar instructions a step on the exec masks of a loop with two exits and a rare side path (beside 23 vector instructions of
-            // work); here a step is 22 vector + 5 scalar instructions + 2 LDS reads.  exec on entry = the lanes that walk; a lane leaves by clearing
-            // its exec bit (its walk is over) or through `stall` (it found the pool full and walks on in the next sweep).
+            // work); here a step is 22 vector + 6 scalar instructions + 2 LDS reads, the reads issued as soon as the next cell is known.  exec on
+            // entry = the lanes that walk; a lane leaves by clearing its exec bit (its walk is over) or through `stall` (it found the pool full and
+            // walks on in the next sweep).  Hazards: none of CDNA3's manually handled ones occur (no DPP, no v_readlane, no VMEM after a VALU-written
+            // SGPR); the compiler itself overwrites an LDS address register right behind the ds_read that used it.
             uint32_t flag, tb, tc, tsh;
-            unsigned long long s_save, s_stall, s_ex, s_ey, s_t;
+            unsigned long long s_save, s_stall, s_ex, s_ey, s_t, s_in;
             const uint32_t pool_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&pt_lds_dyn[wbase + (uint32_t)CW_POOL * 64u];
             const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&pt_lds_dyn[toff];
             const uint32_t lane24 = lane << 24;
@@ -230,31 +232,31 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
                 // the step (code.cl:1028-1066): the axis whose plane the ray reached -- x before y before z -- moves on
                 "v_cmp_eq_f32_e64 %[ex], %[cmax], %[tnx]\n\t"
                 "v_cmp_eq_f32_e64 %[ey], %[cmax], %[tny]\n\t"
-                "v_add_f32_e32 %[a], %[tnx], %[dtx]\n\t"
-                "v_add_f32_e32 %[b], %[tny], %[dty]\n\t"
-                "v_add_f32_e32 %[c], %[tnz], %[dtz]\n\t"
+                "v_cmp_nge_f32_e32 vcc, %[cmax], %[tend]\n\t"
                 "s_or_b64 %[t], %[ex], %[ey]\n\t"
                 "s_andn2_b64 %[ey], %[ey], %[ex]\n\t"
-                "v_cndmask_b32_e64 %[tnx], %[tnx], %[a], %[ex]\n\t"
-                "v_cndmask_b32_e64 %[tnz], %[c], %[tnz], %[t]\n\t"
-                "v_cndmask_b32_e64 %[tny], %[tny], %[b], %[ey]\n\t"
                 "v_cndmask_b32_e64 %[sh], 20, 10, %[ey]\n\t"
                 "v_cndmask_b32_e64 %[sh], %[sh], 0, %[ex]\n\t"
                 "v_cndmask_b32_e64 %[a], %[scz], %[scy], %[ey]\n\t"
-                "v_cndmask_b32_e64 %[a], %[a], %[scx], %[ex]\n\t"
                 "v_bfe_u32 %[b], %[pk], %[sh], 10\n\t"
-                "v_cmp_nge_f32_e32 vcc, %[cmax], %[tend]\n\t"
-                "v_cmp_ne_u32_e64 %[t], 0, %[b]\n\t"
-                "v_lshl_add_u32 %[pk], -1, %[sh], %[pk]\n\t"
+                "v_cndmask_b32_e64 %[a], %[a], %[scx], %[ex]\n\t"
+                "v_cmp_ne_u32_e64 %[save2], 0, %[b]\n\t"
                 "v_add_u32_e32 %[cell], %[cell], %[a]\n\t"
-                "s_and_b64 vcc, vcc, %[t]\n\t"
+                "s_and_b64 vcc, vcc, %[save2]\n\t"
                 "s_and_b64 exec, exec, vcc\n\t"
                 "s_cbranch_execz .Lcoop_done_%=\n\t"
-                // the next cell: its window and its list
+                // the next cell's list: asked for before the rest of the step, which does not need it
                 "v_lshl_add_u32 %[a], %[cell], 2, %[tbase]\n\t"
-                "v_mov_b32_e32 %[cmin], %[cmax]\n\t"
                 "ds_read_b32 %[i], %[a]\n\t"
                 "ds_read_b32 %[end], %[a] offset:4\n\t"
+                "v_add_f32_e32 %[a], %[tnx], %[dtx]\n\t"
+                "v_add_f32_e32 %[b], %[tny], %[dty]\n\t"
+                "v_add_f32_e32 %[c], %[tnz], %[dtz]\n\t"
+                "v_lshl_add_u32 %[pk], -1, %[sh], %[pk]\n\t"
+                "v_mov_b32_e32 %[cmin], %[cmax]\n\t"
+                "v_cndmask_b32_e64 %[tnx], %[tnx], %[a], %[ex]\n\t"
+                "v_cndmask_b32_e64 %[tny], %[tny], %[b], %[ey]\n\t"
+                "v_cndmask_b32_e64 %[tnz], %[c], %[tnz], %[t]\n\t"
                 "v_min3_f32 %[cmax], %[tnx], %[tny], %[tnz]\n\t"
                 "s_branch .Lcoop_top_%=\n"
                 ".Lcoop_done_%=:\n\t"
@@ -262,7 +264,7 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
                 "v_cndmask_b32_e64 %[a], 0, 1, %[stall]"
                 : [tnx] "+v"(tnx), [tny] "+v"(tny), [tnz] "+v"(tnz), [pk] "+v"(pk), [cell] "+v"(cell), [cmin] "+v"(cmin), [cmax] "+v"(cmax), [i] "+v"(i), [end] "+v"(end),
                   [a] "=&v"(flag), [b] "=&v"(tb), [c] "=&v"(tc), [sh] "=&v"(tsh),
-                  [save] "=&s"(s_save), [stall] "=&s"(s_stall), [ex] "=&s"(s_ex), [ey] "=&s"(s_ey), [t] "=&s"(s_t)
+                  [save] "=&s"(s_save), [stall] "=&s"(s_stall), [ex] "=&s"(s_ex), [ey] "=&s"(s_ey), [t] "=&s"(s_t), [save2] "=&s"(s_in)
                 : [dtx] "v"(dtx), [dty] "v"(dty), [dtz] "v"(dtz), [scx] "v"(scx), [scy] "v"(scy), [scz] "v"(scz), [tend] "v"(tend), [lane24] "v"(lane24),
                   [pool] "v"(pool_addr), [tbase] "s"(tbase)
                 : "vcc", "scc", "memory");
