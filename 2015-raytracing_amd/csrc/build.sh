@@ -15,11 +15,12 @@ SRC=("${HERE}/mirt_abi.cpp" "${HERE}/pt_kernels_granular.hip" "${HERE}/pt_kernel
 # libmirt_default.so -- the SECOND numerics contract: the reference as its own host builds it, program.build() without options (A10 code.js:599),
 # i.e. AMD's default 2.5-ulp division and 3-ulp sqrt.  Same sources: -fno-hip-fp32-correctly-rounded-divide-sqrt makes every `/` and sqrt the
 # sequence AMD's OpenCL compiler emits without -cl-fp32-correctly-rounded-divide-sqrt (the same LLVM lowering: frexp-scaled v_rcp_f32, ldexp-scaled
-# v_sqrt_f32); PT_PLAIN_DIV spells the divisions as divisions, PT_EXACT_FAST_DIV=0 leaves only the kernel that divides where the reference divides
-# (the optimistic kernel's shared reciprocals are exact-division identities, not this contract's).  Same C ABI, a drop-in file; pyhost picks it with
-# MIRT_CONTRACT=default.  Built only for the default output path (an A/B build names its own).
+# v_sqrt_f32); PT_PLAIN_DIV spells every division of the kernels as a division on the reference's operands -- the refined-reciprocal forms of the
+# optimistic kernel are exact-division identities, not this contract's -- and keeps that kernel's STRUCTURE (candidate lists, plane list, shared-test walk,
+# guard windows with the exact kernel behind them), which does not depend on how a quotient is rounded.  Same C ABI, a drop-in file;
+# pyhost picks it with MIRT_CONTRACT=default.  Built only for the default output path (an A/B build names its own).
 if [ -z "${MIRT_OUT:-}" ] && [ "${MIRT_SKIP_DEFAULT_CONTRACT:-0}" != 1 ]; then
-    "${HIPCC}" "${FLAGS[@]/-fhip-fp32-correctly-rounded-divide-sqrt/-fno-hip-fp32-correctly-rounded-divide-sqrt}" -DPT_PLAIN_DIV=1 -DPT_EXACT_FAST_DIV=0 \
+    "${HIPCC}" "${FLAGS[@]/-fhip-fp32-correctly-rounded-divide-sqrt/-fno-hip-fp32-correctly-rounded-divide-sqrt}" -DPT_PLAIN_DIV=1 \
         -shared -o "${HERE}/../libmirt_default.so" "${SRC[@]}" "$@" &
 fi
 "${HIPCC}" "${FLAGS[@]}" -shared -o "${OUT}" "${SRC[@]}" "$@"

@@ -324,13 +324,18 @@ PT_DEV bool sph_test(f3 o, f3 d, const SphereRay& sr, float cmin, float cmax, co
 // axis_setup (pt_device.hpp) with the optimistic kernel's divisions: every quotient is div_exact3 on a refined reciprocal.  The
 // denominators are the ray direction (ray_guard), the slab count and the slab width; numerators and the slab width are checked
 // here, per lane, and a lane outside the windows marks its sample for the exact kernel.
-PT_DEV bool num_window(float v) { const float a = __builtin_fabsf(v); return (v == 0.0f) | ((a >= 8.6736174e-19f) & (a <= 1.1529215e18f)); }   // 0 | 2^-60 .. 2^60
+PT_DEV bool num_window(float v) { const float a = __builtin_fabsf(v); return ((int)(v == 0.0f) | ((int)(a >= 8.6736174e-19f) & (int)(a <= 1.1529215e18f))) != 0; }   // 0 | 2^-60 .. 2^60
 PT_DEV bool den_window(float v) { const float a = __builtin_fabsf(v); return a >= 9.094947e-13f && a <= 1.0995116e12f; }                    // 2^-40 .. 2^40
 // The slab width delta = (hi - lo) / n and 1 / delta depend on the set alone: the host computes them once (GridArgs::delta / rdelta,
 // correctly rounded, which is what div_exact3 / rcp_refined give inside their windows; GridArgs::walk_ok says the windows hold).
 template <bool FAST>
 PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint32_t n, float delta, float rdelta, float rd, bool& defer) {   // rd = rcp_refined(d): the ray's, made once (RayRcp)
     if (!FAST) return axis_setup(o, d, tmin, lo, hi, n);
+#if PT_PLAIN_DIV
+    // the default contract (libmirt_default.so): the slab width is the reference's own quotient (code.cl:699) in THIS contract's 2.5-ulp division; the host's
+    // GridArgs::delta is the correctly rounded one, which is not always the same float.  (The argument is wave-uniform: the compiler divides once per walk.)
+    delta = (hi - lo) / (float)n;
+#endif
     Axis a;
     const float x = cl_fma(tmin, d, o);                    // code.cl:698
     const float num0 = x - lo;
@@ -347,7 +352,7 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     a.tnext = div_exact3(num1, d, rd);
     // (bitwise on purpose: with || and && the compiler branches around the second window of a lane that already defers -- a dozen scalar instructions
     // and a block boundary per axis of every walk, to save six compares nobody waits for)
-    defer = defer | !(num_window(num0) & num_window(num1));
+    defer = ((int)defer | (int)!((int)num_window(num0) & (int)num_window(num1))) != 0;
     return a;
 }
 

@@ -10,6 +10,9 @@ tail -1 "${OUT}/gpu_tests.txt"
 timeout -k 10 600 python bench.py > "${OUT}/bench.json" 2> "${OUT}/bench.err" || exit 22
 timeout -k 10 300 python bench.py --scene cornell_teapot3 --no-cpu > "${OUT}/bench_teapot3.json" 2> "${OUT}/bench_teapot3.err" || exit 23
 timeout -k 10 300 python profiles/scene_bench.py > "${OUT}/scene_bench.txt" 2>&1 || exit 24
+# the second numerics contract (libmirt_default.so: the reference as its own host builds it), same two bench lines
+MIRT_CONTRACT=default timeout -k 10 300 python bench.py --no-cpu --no-extras --no-depth5 > "${OUT}/bench_default_contract.json" 2> "${OUT}/bench_default_contract.err" || exit 32
+MIRT_CONTRACT=default timeout -k 10 300 python bench.py --scene cornell_teapot3 --no-cpu --no-extras > "${OUT}/bench_default_contract_teapot3.json" 2>> "${OUT}/bench_default_contract.err" || exit 33
 timeout -k 10 300 python profiles/granular_bench.py > "${OUT}/granular.txt" 2>&1 || exit 25
 timeout -k 10 300 python profiles/grid_split.py > "${OUT}/grid_split.txt" 2>&1 || exit 26
 timeout -k 10 900 bash profiles/run_profile.sh "${TAG}" > "${OUT}/run_profile.log" 2>&1 || exit 27

@@ -42,27 +42,68 @@ def scenes(mirt, render, scene):
         k = G.GpuRefKernels(DEFAULT_HSACO)
         st = A.PassState(sc, seeds)
         ctx = mirt.Context(0)
-        fr = render.FusedRenderer(ctx, ps, seeds=seeds)
         try:
             for p in range(2):
                 A.run_pass(k, sc, st, bounces=8, init_acu=(p == 0))
-                fr.execute_render(bounces=8)
-            for tag, got, want in (("accumulators", fr.acu.read(np.float32), st.acu), ("seeds", fr.seeds.read(np.int32), st.seeds),
-                                   ("pixels", fr.pixel.read(np.uint8), st.pixel)):
-                d = first_difference(f"{name} {tag}", np.asarray(got), np.asarray(want))
-                if d:
-                    print(json.dumps({"check": "scenes", "scene": name, "ok": False, "difference": d}), flush=True)
-                    return False
+            for exact_only in (False, True):   # the optimistic pair (the default), then the exact kernel alone
+                ctx.set_exact_only(exact_only)
+                fr = render.FusedRenderer(ctx, ps, seeds=seeds)
+                for p in range(2):
+                    fr.execute_render(bounces=8)
+                checks = (("accumulators", fr.acu.read(np.float32), st.acu), ("seeds", fr.seeds.read(np.int32), st.seeds), ("pixels", fr.pixel.read(np.uint8), st.pixel))
+                fr.release()
+                for tag, got, want in checks:
+                    d = first_difference(f"{name} exact_only={exact_only} {tag}", np.asarray(got), np.asarray(want))
+                    if d:
+                        print(json.dumps({"check": "scenes", "scene": name, "ok": False, "difference": d}), flush=True)
+                        return False
             print(json.dumps({"check": "scenes", "scene": name, "ok": True, "samples": 2 * sc.total_rays}), flush=True)
         finally:
             k.release()
-            fr.release()
             ctx.destroy()
     return True
 
 
+def random_scenes(mirt, render, scene, count):
+    """`count` generated scenes (tests/test_random_scenes.py: one to three loose and grid sets, grids of 1..7 cells per axis, crowded and empty cells, one to
+    three lights) -- the optimistic pair, the exact kernel alone and the pass that resolves its own pixels, each against the reference's default build."""
+    from test_random_scenes import random_scene
+    _, base = load_fixture("cornell_teapot3_32x24_r4")
+    k = G.GpuRefKernels(DEFAULT_HSACO)
+    ctx = mirt.Context(0)
+    try:
+        for seed in range(count):
+            sc = random_scene(base, 1000 + seed, rpp=4)   # (four rays per pixel: at one, the reference's initTrace races on seeds[column] on a GPU)
+            seeds = A.make_seeds(sc.total_rays, seed_base=seed)
+            st = A.PassState(sc, seeds)
+            A.run_pass(k, sc, st)
+            for exact_only in (False, True):
+                ctx.set_exact_only(exact_only)
+                fr = render.FusedRenderer(ctx, sc, seeds=seeds)
+                fr.execute_render()
+                checks = [("accumulators", fr.acu.read(np.float32), st.acu), ("seeds", fr.seeds.read(np.int32), st.seeds), ("pixels", fr.pixel.read(np.uint8), st.pixel)]
+                fr.release()
+                fr = render.FusedRenderer(ctx, sc, seeds=seeds, keep_acu=False)
+                fr.execute_render(fresh=True)
+                checks += [("seeds (in-pass resolve)", fr.seeds.read(np.int32), st.seeds), ("pixels (in-pass resolve)", fr.pixel.read(np.uint8), st.pixel)]
+                fr.release()
+                for tag, got, want in checks:
+                    d = first_difference(f"random scene {seed}, exact_only={exact_only}, {tag}", np.asarray(got), np.asarray(want))
+                    if d:
+                        print(json.dumps({"check": "random", "seed": seed, "ok": False, "difference": d}), flush=True)
+                        return False
+            if seed % 100 == 99:
+                print(json.dumps({"check": "random", "ok": True, "scenes_so_far": seed + 1}), flush=True)
+        print(json.dumps({"check": "random", "ok": True, "scenes": count}), flush=True)
+    finally:
+        ctx.set_exact_only(False)
+        k.release()
+        ctx.destroy()
+    return True
+
+
 def headline(mirt, render, scene):
-    """BASELINE's headline frame at full size: 1920x1080 x 256 rays per pixel, depth 8 (530 841 600 samples)."""
+    """BASELINE's headline frame at full size: 1920x1080 x 256 rays per pixel, depth 8 (530 841 600 samples): the optimistic pair, then the exact kernel alone."""
     import ctypes as C
     base = scene.PackedScene(open(os.path.join(ROOT, "tests", "golden", "scene_cornell_1920x1080_r256.json")).read())
     sc = A.Scene(base.d)
@@ -70,8 +111,7 @@ def headline(mirt, render, scene):
     ctx = mirt.Context(0)
     fr = render.FusedRenderer(ctx, base, want_radiance=False)
     seeds = fr.seeds.read(np.int32)
-    fr.execute_render(bounces=8, fresh=True)
-    ctx.finish()
+    fr.release()
     k = G.GpuRefKernels(DEFAULT_HSACO)
 
     class St:
@@ -83,31 +123,40 @@ def headline(mirt, render, scene):
     st.seeds.upload(seeds)
     del seeds
     A.run_pass(k, sc, st, bounces=8)
-    ok = True
+    for b in (st.rays, st.pois, st.shadow):
+        b.free()
+    want_pixel, want_seeds = st.pixel.download(np.uint8, npix * 4), st.seeds.download(np.int32, n)
     try:
-        for tag, got, want in (("pixels", fr.pixel.read(np.uint8), st.pixel.download(np.uint8, npix * 4)),
-                               ("seeds", fr.seeds.read(np.int32), st.seeds.download(np.int32, n))):
-            d = first_difference("headline " + tag, got, want)
-            if d:
-                print(json.dumps({"check": "headline", "ok": False, "difference": d}), flush=True)
-                return False
-        chunk = 1 << 26
-        for off in range(0, 4 * n, chunk):
-            m = min(chunk, 4 * n - off)
-            want = np.empty(m, np.float32)
-            G.chk(G.hip().hipMemcpy(want.ctypes.data_as(C.c_void_p), C.c_void_p(st.acu.ptr + 4 * off), 4 * m, 2), "D2H")
-            d = first_difference(f"headline accumulators [{off}, {off + m})", fr.acu.read(np.float32, count=m, offset=4 * off), want)
-            if d:
-                print(json.dumps({"check": "headline", "ok": False, "difference": d}), flush=True)
-                return False
+        for exact_only in (False, True):
+            ctx.set_exact_only(exact_only)
+            fr = render.FusedRenderer(ctx, base, want_radiance=False)   # (the same seed fill as the one the reference started from)
+            fr.execute_render(bounces=8, fresh=True)
+            ctx.finish()
+            try:
+                for tag, got, want in (("pixels", fr.pixel.read(np.uint8), want_pixel), ("seeds", fr.seeds.read(np.int32), want_seeds)):
+                    d = first_difference(f"headline exact_only={exact_only} {tag}", got, want)
+                    if d:
+                        print(json.dumps({"check": "headline", "ok": False, "difference": d}), flush=True)
+                        return False
+                chunk = 1 << 26
+                for off in range(0, 4 * n, chunk):
+                    m = min(chunk, 4 * n - off)
+                    want = np.empty(m, np.float32)
+                    G.chk(G.hip().hipMemcpy(want.ctypes.data_as(C.c_void_p), C.c_void_p(st.acu.ptr + 4 * off), 4 * m, 2), "D2H")
+                    d = first_difference(f"headline exact_only={exact_only} accumulators [{off}, {off + m})", fr.acu.read(np.float32, count=m, offset=4 * off), want)
+                    if d:
+                        print(json.dumps({"check": "headline", "ok": False, "difference": d}), flush=True)
+                        return False
+            finally:
+                fr.release()
     finally:
-        for b in (st.rays, st.pois, st.shadow, st.acu, st.seeds, st.pixel):
+        for b in (st.acu, st.seeds, st.pixel):
             b.free()
         k.release()
-        fr.release()
+        ctx.set_exact_only(False)
         ctx.destroy()
-    print(json.dumps({"check": "headline", "ok": ok, "samples": n}), flush=True)
-    return ok
+    print(json.dumps({"check": "headline", "ok": True, "samples": n}), flush=True)
+    return True
 
 
 def main():
@@ -119,6 +168,8 @@ def main():
     ok = True
     if "scenes" in which:
         ok = scenes(mirt, render, scene) and ok
+    if ok and "random" in which:
+        ok = random_scenes(mirt, render, scene, int(os.environ.get("MIRT_SOAK", "64"))) and ok
     if ok and "headline" in which:
         ok = headline(mirt, render, scene) and ok
     sys.exit(0 if ok else 1)

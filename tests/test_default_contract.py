@@ -38,6 +38,16 @@ def test_every_scene_equals_the_default_build_of_the_reference():
 
 @pytest.mark.gpu
 @needs
+def test_generated_scenes_equal_the_default_build_of_the_reference():
+    """64 generated scenes (MIRT_SOAK=N: N) with grids of 1..7 cells per axis: the optimistic pair -- since round 4 this library has one: the optimistic
+    kernel's structure with every quotient a plain division -- the exact kernel alone, and the in-pass resolve, against the reference's default build"""
+    r, lines = run_check("random")
+    assert r.returncode == 0, (lines[-1:] or r.stderr[-2000:])
+    assert lines and lines[-1]["ok"]
+
+
+@pytest.mark.gpu
+@needs
 def test_headline_frame_equals_the_default_build_of_the_reference():
     """cornell.xml 1920x1080 x 256 rays per pixel, depth 8: 530 841 600 samples"""
     r, lines = run_check("headline")

@@ -44,7 +44,9 @@ def _pack_tris(v, n, order):
     return pos.ravel().tolist(), nor.ravel().tolist()
 
 
-def random_scene(base, seed):
+def random_scene(base, seed, rpp=None):
+    """rpp: the rays per pixel instead of the scene's own draw (1 or 4) -- for checks against the reference binary ON the GPU, where initTrace at one ray
+    per pixel races on seeds[column] (oracle/ref_gpu.py)"""
     rng = np.random.default_rng(seed)
     d = dict(base.d)
     nmat = len(d["materials"]) // 4
@@ -82,7 +84,8 @@ def random_scene(base, seed):
     out["meshes"] = meshes
     out["lights"] = [d["lights"][i % len(d["lights"])] for i in range(int(rng.integers(1, 4)))]
     w = int(os.environ.get("MIRT_SOAK_W", "48"))
-    return _variant(base, width=w, height=max(1, w * 9 // 16), rays_per_pixel=int(rng.choice([1, 4])), **out)
+    own = int(rng.choice([1, 4]))
+    return _variant(base, width=w, height=max(1, w * 9 // 16), rays_per_pixel=rpp or own, **out)
 
 
 # MIRT_SOAK=N: N scenes instead of 16 (a longer hunt for a rare disagreement; not part of the default run)
