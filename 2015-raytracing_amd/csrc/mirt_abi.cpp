@@ -80,7 +80,9 @@ struct mirt_ctx {
     size_t defer_bytes = 0;
     uint32_t defer_words = 0;     // mask words the last mirt_render_pass used (0: it ran the exact kernel only)
     uint32_t defer_unit = 1;      // samples per mask bit: 1, or 256 when that pass resolved its pixels itself (a bit per block)
-    bool inpass_resolve = true;   // a frame's first pass writes pixel / radiance itself where it can (MIRT_INPASS_RESOLVE=0: always the separate copyToPixel)
+    bool inpass_resolve = true;   // a pass writes pixel / radiance itself where it can (MIRT_INPASS_RESOLVE=0: always the separate copyToPixel)
+    bool last_pass_resolved = false;   // render_pass_impl: the pass just queued resolved its own pixels
+    float res_m_override = NAN;        // try_fuse_pass -> render_pass_impl: the tone factor of the recorded copyToPixel, as the host passed it
     int force_exact = 0;          // mirt_ctx_set_exact_only: 1 = skip the optimistic kernel, run every sample through the exact one
     bool profiling = false;       // per-kernel events inside mirt_render_pass
     hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
@@ -1024,11 +1026,15 @@ static int try_fuse_pass(mirt_ctx* ctx, std::vector<mirt_ctx::Pending>& P) {
     for (size_t l = 0; l < lights.size(); ++l) { memcpy(ls[l].light, lights[l].light, 64); memcpy(ls[l].shadow, lights[l].shadow, 64); memcpy(ls[l].scene, lights[l].scene, 64); }
     d.lights = ls.data(); d.n_lights = (uint32_t)ls.size();
     d.material = material; d.seeds = seeds; d.acu = acu;
+    // the recorded copyToPixel goes into the pass where the pass can resolve its own pixels (whole pixels per block of 256 ray ids): its pixel buffer and
+    // its factor as the host passed it; where it cannot, render_pass_impl queues the separate kernel behind the pass, with that factor
+    d.pixel = PB(i, 0);
+    ctx->res_m_override = PF(i, 2);
     int rc = render_pass_impl(ctx, &d, false);
+    ctx->res_m_override = NAN;
     if (rc && rc != MIRT_E_DEVICE) return 1;   // refused before anything was launched (a size, a grid that fails validation ...): run the stream as issued,
     if (rc) return rc;                          // whose own checks then report it against the kernel that trips it
-    rc = launch_kernel(ctx, *P[i].spec, P[i].args, P[i].dim, P[i].g);
-    if (rc) return rc;
+    PB(i, 0)->version++;   // (written by the pass itself, or by the copyToPixel render_pass_impl queued behind it with the recorded factor)
     ctx->fused_passes++;
     return MIRT_OK;
 #undef PB
@@ -1379,8 +1385,9 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     if ((rc = need(ctx, "seeds", d->seeds, nrays * 4))) return rc;
     // copyToPixel inside the pass: a frame's first pass at a ray count that puts whole pixels into a block of 256 ray ids (pt_launch.hpp
     // fused_resolves).  Then -- and only then -- `acu` is optional: without it nothing per ray but the seed touches memory.
-    const bool resolve_in_pass = ctx->inpass_resolve && pt::fused_resolves(d->rays_per_pixel, fresh, d->pixel || d->radiance);
-    if (!d->acu && !resolve_in_pass)
+    const bool resolve_in_pass = ctx->inpass_resolve && pt::fused_resolves(d->rays_per_pixel, d->pixel || d->radiance) && (fresh || d->acu);
+    ctx->last_pass_resolved = resolve_in_pass;
+    if (!d->acu && !(resolve_in_pass && fresh))
         return fail(ctx, MIRT_E_ARG, "mirt_render_pass: acu may only be null for a frame's first pass (mirt_render_first_pass) with a pixel or radiance buffer and "
                                      "rays_per_pixel dividing 256 or 256 times a power of two up to 32 (here: %s, %u rays per pixel%s)", fresh ? "first pass" : "NOT a first pass",
                     d->rays_per_pixel, d->pixel || d->radiance ? "" : ", no output buffer");
@@ -1396,6 +1403,7 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
         A.pixel = d->pixel ? d->pixel->ptr : nullptr;
         A.radiance = d->radiance ? d->radiance->ptr : nullptr;
         A.res_m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
+        if (ctx->res_m_override == ctx->res_m_override) A.res_m = ctx->res_m_override;   // (not a NaN: try_fuse_pass hands over the recorded copyToPixel's own factor)
         A.chunks = pt::fused_chunks(d->rays_per_pixel);
         if (A.chunks > 1u && !A.radiance) {   // a pixel of more than 256 rays: its sums travel from launch to launch through memory (FusedArgs::chunks)
             if ((rc = ensure_scratch(ctx, (size_t)npix * 16))) return rc;
@@ -1455,7 +1463,8 @@ static int render_pass_impl(mirt_ctx* ctx, const mirt_pass_desc* d, bool fresh) 
     }
     if (ctx->profiling && !ctx->capturing) HIPCHK(ctx, hipEventRecord(ctx->pe[1], ctx->stream));
     if (!resolve_in_pass && (d->pixel || d->radiance)) {
-        const float m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
+        float m = (float)(1.0 / ((double)d->rays_per_pixel * (double)d->pass_index));  // A10 code.js:1412
+        if (ctx->res_m_override == ctx->res_m_override) m = ctx->res_m_override;
         pt::launch_copyToPixel(ctx->stream, d->pixel ? d->pixel->ptr : nullptr, A.acu, m, (uint32_t)npix, A.rpp, (uint32_t)npix,
                                d->radiance ? d->radiance->ptr : nullptr);
     }

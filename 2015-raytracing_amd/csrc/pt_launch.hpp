@@ -105,11 +105,12 @@ struct FusedArgs {
     uint32_t chunk;          // this launch's c
     uint32_t chunk_bits;     // redo mode: the bits of a 32-block mask word that are blocks of this launch (all ones when chunks == 1)
 };
-// whether a pass with these arguments resolves inside the kernel: first pass of a frame, whole pixels per block (or whole blocks per pixel, see
-// FusedArgs::chunks), somewhere to put the result
+// whether a pass with these arguments resolves inside the kernel: whole pixels per block (or whole blocks per pixel, see FusedArgs::chunks) and
+// somewhere to put the result.  A frame's first pass may then do without `acu`; a later pass reads and writes it as ever -- the block's LDS holds the
+// accumulators as the pass leaves them, which is what the separate copyToPixel would read back.
 inline uint32_t fused_chunks(uint32_t rpp) { return rpp > 256u ? rpp / 256u : 1u; }
-inline bool fused_resolves(uint32_t rpp, bool fresh, bool want_out) {
-    if (!fresh || !want_out || rpp == 0u) return false;
+inline bool fused_resolves(uint32_t rpp, bool want_out) {
+    if (!want_out || rpp == 0u) return false;
     if (rpp <= 256u) return 256u % rpp == 0u;
     const uint32_t c = rpp / 256u;
     return rpp % 256u == 0u && c <= 32u && (c & (c - 1u)) == 0u;

@@ -190,6 +190,9 @@ MIRT_API int mirt_render_pass(mirt_ctx* ctx, const mirt_pass_desc* desc);
  * 16 bytes per ray are never allocated; with `acu` given it is written as before (what a second progressive pass needs).  Results
  * are bit-identical either way.  In this mode the optimistic / exact kernel pair hands over whole blocks of 256 samples
  * (mirt_pass_deferred counts them as such).  MIRT_INPASS_RESOLVE=0 in the environment keeps the separate copyToPixel.
+ * A LATER pass (mirt_render_pass) with a pixel or radiance buffer resolves inside the pass under the same condition -- `acu` is then read and
+ * written as ever, and the separate copyToPixel's second read of it is saved; the runtime's command-stream fusion (mirt_ctx_set_fusion) folds the
+ * host's recorded copyToPixel into the pass the same way, with the factor the host passed.
  * MORE than 256 rays per pixel, 256 times a power of two up to 32 (the squares among them: 1024 = BASELINE config 5's 32 x 32 lens grid,
  * and 4096): a pixel spans 4 (16) blocks, so the pass is queued as 4 (16) launches, launch c rendering the c-th block of every pixel and
  * going on from the sums launch c - 1 left in `radiance` (or in the context's scratch buffer when the caller passes none): the

@@ -549,7 +549,9 @@ def test_headline_frame_two_exact_routes_agree(ctx, pkg):
         finally:
             ctx.set_exact_only(False)
     (r0, p0, s0, d0), (r1, p1, s1, d1) = out
-    assert d1 == 0 and 0 < d0 < 10000                      # a few hundred samples per frame leave the guard windows
+    # a few hundred samples per frame leave the guard windows; the pass resolves its own pixels (later passes too, since round 4), so the exact kernel
+    # re-runs the BLOCKS of 256 that hold one and the count is in whole blocks
+    assert d1 == 0 and 0 < d0 < 1000 * 256 and d0 % 256 == 0
     assert np.array_equal(bits(r0), bits(r1)) and np.array_equal(p0, p1) and np.array_equal(s0, s1)
     assert (p0.reshape(-1, 4)[:, :3].max(axis=1) > 0).mean() > 0.9
 
