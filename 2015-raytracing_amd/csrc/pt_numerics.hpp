@@ -142,6 +142,15 @@ PT_DEV float div_exact3(float n, float d, float r) {
     float q = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0);
     return (n == 0.0f) ? q0 : q;
 }
+// div_exact3 for a quotient whose zero's SIGN nobody can see (it is converted to an integer, or only ever compared, added to and passed through
+// min / max): without the select that hands a zero numerator's sign over -- for n = +-0 this returns a zero of either sign
+PT_DEV float div_exact3_anyzero(float n, float d, float r) {
+#if PT_PLAIN_DIV
+    return n / d;
+#endif
+    const float q0 = n * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0);
+}
 PT_DEV bool rcp_window(float x) { return (__float_as_uint(x) & 0x7FFFFFFFu) - 0x00800000u < 0x7E800000u - 0x00800000u; }   // normal, < 2^126 (one unsigned compare)
 // 1.0f/x, bit for bit.  `dont_care`: lanes whose result is never used (they must not force the slow path).
 PT_DEV float rcp_exact(float x, bool dont_care = false) {

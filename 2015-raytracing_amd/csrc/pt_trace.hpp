@@ -340,16 +340,17 @@ PT_DEV Axis axis_setup_t(float o, float d, float tmin, float lo, float hi, uint3
     const float x = cl_fma(tmin, d, o);                    // code.cl:698
     const float num0 = x - lo;
     {   // if (slab < 0) slab = 0; if (slab >= n) slab = n - 1 (code.cl:699-700), spelled so that it is one v_med3_i32
-        const int q = f2i(div_exact3(num0, delta, rdelta)), top = (int)(n - 1u), q0 = q > 0 ? q : 0;
+        const int q = f2i(div_exact3_anyzero(num0, delta, rdelta)), top = (int)(n - 1u), q0 = q > 0 ? q : 0;   // (a zero of either sign converts to 0)
         a.slab = q0 < top ? q0 : top;
     }
     const bool fwd = d >= 0;
     a.dslab = fwd ? 1 : -1;
     a.limit = fwd ? (int)n : -1;
-    a.dt = div_exact3(delta, cl_fabs(d), cl_fabs(rd));   // rcp_refined is odd in d: every step is sign-symmetric under RNE
+    a.dt = div_exact3_anyzero(delta, cl_fabs(d), cl_fabs(rd));   // rcp_refined is odd in d: every step is sign-symmetric under RNE; delta != 0 (GridArgs::walk_ok)
     const float xnext = cl_fma((float)(a.slab + (fwd ? 1 : 0)), delta, lo);   // code.cl:706
     const float num1 = xnext - o;
-    a.tnext = div_exact3(num1, d, rd);
+    // (the sign of a zero tnext is invisible: the walk compares it, adds the positive dt to it and passes it through v_min3_f32 into windows that are only compared)
+    a.tnext = div_exact3_anyzero(num1, d, rd);
     // (bitwise on purpose: with || and && the compiler branches around the second window of a lane that already defers -- a dozen scalar instructions
     // and a block boundary per axis of every walk, to save six compares nobody waits for)
     defer = ((int)defer | (int)!((int)num_window(num0) & (int)num_window(num1))) != 0;
