@@ -57,7 +57,7 @@ constexpr uint32_t kCoopMaxCell = kMaxCellSlots; // slots one cell may hold (the
 
 template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
 PT_DEV uint32_t dpp_or0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, BOUND); }
-// inclusive prefix sum / prefix maximum over the 64 lanes (all active): four shifts inside each row of 16, then the row totals
+// inclusive prefix sum over the 64 lanes (all active): four shifts inside each row of 16, then the row totals
 // carried to the next row and to the upper half (row_bcast:15, row_bcast:31)
 PT_DEV uint32_t wave_scan_add(uint32_t v) {
     v += dpp_or0<0x111, 0xf, 0xf, true>(v);
@@ -66,16 +66,6 @@ PT_DEV uint32_t wave_scan_add(uint32_t v) {
     v += dpp_or0<0x118, 0xf, 0xf, true>(v);
     v += dpp_or0<0x142, 0xa, 0xf, false>(v);
     v += dpp_or0<0x143, 0xc, 0xf, false>(v);
-    return v;
-}
-PT_DEV uint32_t umax2(uint32_t a, uint32_t b) { return a > b ? a : b; }
-PT_DEV uint32_t wave_scan_max(uint32_t v) {
-    v = umax2(v, dpp_or0<0x111, 0xf, 0xf, true>(v));
-    v = umax2(v, dpp_or0<0x112, 0xf, 0xf, true>(v));
-    v = umax2(v, dpp_or0<0x114, 0xf, 0xf, true>(v));
-    v = umax2(v, dpp_or0<0x118, 0xf, 0xf, true>(v));
-    v = umax2(v, dpp_or0<0x142, 0xa, 0xf, false>(v));
-    v = umax2(v, dpp_or0<0x143, 0xc, 0xf, false>(v));
     return v;
 }
 // LDS traffic between lanes of one wave: the LDS executes a wave's instructions in order; this keeps the compiler from moving them
@@ -309,13 +299,19 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
         pt_count(PC_GRID_PAIRS + PCK, false, total);
         for (uint32_t base = 0u; base < total; base += 64u) {
             pt_count(PC_GRID_ROUNDS + PCK);
-            // which record pair base + lane belongs to: records mark the first pair of theirs inside this window, a prefix maximum spreads the mark
+            // which record pair base + lane belongs to: records mark the first pair of theirs inside this window; the records of a window are
+            // consecutive, so a pair's record is the one that marked pair `base` plus the marks between the two -- one ballot and a v_mbcnt pair
+            // (a DPP prefix maximum over the marks before: six dependent DPP operations and their wait states per round)
             CW_MINE(CW_OWN) = 0u;
             if (cnt != 0u && excl < base + 64u && incl > base) CW_OF(CW_OWN, (excl > base ? excl : base) - base) = lane + 1u;
             wave_fence();
-            const uint32_t mark = wave_scan_max(CW_MINE(CW_OWN));
+            const uint32_t own_mark = CW_MINE(CW_OWN);
+            const bool marked = own_mark != 0u;
+            const unsigned long long marks = __builtin_amdgcn_ballot_w64(marked);
+            const uint32_t first_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)own_mark) - 1u;   // (pair `base` exists: its record marked lane 0)
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u));
             const uint32_t p = base + lane;
-            const uint32_t r = mark != 0u ? mark - 1u : 0u;   // (a lane without a pair asks record 0 and drops the answers)
+            const uint32_t r = (first_rec - 1u + below + (marked ? 1u : 0u)) & 63u;   // (a lane past the last pair asks some record and drops the answers)
             const uint32_t rexcl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(r << 2), (int)excl);
             const uint4 rec = pool[r];
             const uint32_t o = rec.y >> 24;
@@ -324,7 +320,7 @@ PT_DEV Hit trace_dda_coop(bool want, const Ray& ray, const RayRcp& rr, const Box
             const float omax = pull(ray.maxt);
             const f3 ro = mk3(pull(ray.o.x), pull(ray.o.y), pull(ray.o.z));
             const f3 rd = mk3(pull(ray.d.x), pull(ray.d.y), pull(ray.d.z));
-            if (p < total && mark != 0u) {
+            if (p < total) {
                 const uint32_t j = p - rexcl;
                 const uint32_t prim = rec.x + j;
                 if (prim < nslots) {
