@@ -686,6 +686,22 @@ def test_config5_one_gpus_share_at_full_size(ctx, pkg):
     print("config5 share:", report)
 
 
+def test_five_wave_variant_of_the_grid_kernels(pkg):
+    """k_fusedPass<true, 1, 5> -- 96 registers, five waves per SIMD, nothing in scratch: the build launch_fused picks when a scene's cell tables
+    leave room for five blocks per CU only -- forced for every grid scene (MIRT_GRID_WAVES=5, read once per process: a process of its own):
+    frames, seeds and accumulators of the fixtures with grid meshes, tolerance 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MIRT_GRID_WAVES="5")
+    env.pop("MIRT_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "grid_waves_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 10 and all(l["ok"] for l in lines), (lines, r.stderr[-1500:])
+
+
 def test_error_paths(ctx, pkg):
     from raytracing_amd.pyhost import mirt
     with pytest.raises(mirt.MirtError) as e:
