@@ -25,6 +25,21 @@ def ctx(pkg):
     c.destroy()
 
 
+@pytest.fixture(scope="module")
+def ctx_sep(pkg):
+    """a context that never resolves in the pass (MIRT_INPASS_RESOLVE=0 is read when a context is created): the separate copyToPixel, as the
+    baseline the in-pass sums are compared with -- since later passes resolve in the pass too, a non-first pass no longer is that baseline"""
+    import os
+    from raytracing_amd.pyhost import mirt
+    os.environ["MIRT_INPASS_RESOLVE"] = "0"
+    try:
+        c = mirt.Context(0)
+    finally:
+        del os.environ["MIRT_INPASS_RESOLVE"]
+    yield c
+    c.destroy()
+
+
 def check_frame(fr, fx, tag, rows=None):
     pix, rad = fx["pixel"], fx["radiance"]
     if rows is not None:
@@ -56,7 +71,7 @@ def test_first_pass_resolves_its_pixels(ctx, pkg, name, keep_acu, exact_only):
         ctx.set_exact_only(False)
 
 
-def test_deferred_blocks_are_rerun_whole(ctx, pkg):
+def test_deferred_blocks_are_rerun_whole(ctx, ctx_sep, pkg):
     """own_flat: axis-parallel geometry, 0.6 % of its samples leave the optimistic kernel's guard windows.  With the pass resolving its
     pixels the exact kernel re-runs every BLOCK that holds one: mirt_pass_deferred counts whole blocks, and the frame is the fixture's."""
     from raytracing_amd.pyhost import render
@@ -67,11 +82,17 @@ def test_deferred_blocks_are_rerun_whole(ctx, pkg):
     check_frame(fr, fx, "own_flat")
     assert np.array_equal(fr.seeds.read(np.int32), fx["f_seeds"])
     fr.release()
-    fr = render.FusedRenderer(ctx, sc, seeds=fx["seeds_in"])
+    fr = render.FusedRenderer(ctx_sep, sc, seeds=fx["seeds_in"])
     fr.execute_render(fresh=False)            # the separate copyToPixel: a bit per sample
-    d_samples = ctx.pass_deferred()
+    d_samples = ctx_sep.pass_deferred()
+    check_frame(fr, fx, "own_flat, separate copyToPixel")
     fr.release()
-    assert d_samples > 0 and d_blocks % 256 == 0 and d_samples <= d_blocks <= 256 * d_samples
+    assert d_samples > 0 and d_samples % 256 != 0 and d_blocks % 256 == 0 and d_samples <= d_blocks <= 256 * d_samples
+    fr = render.FusedRenderer(ctx, sc, seeds=fx["seeds_in"])
+    fr.execute_render(fresh=False)            # a later pass (the accumulator read and written) resolves in the pass as well: whole blocks again
+    assert ctx.pass_deferred() == d_blocks
+    check_frame(fr, fx, "own_flat, non-first pass")
+    fr.release()
 
 
 @pytest.mark.parametrize("name", ["cornell_teapot3_32x24_r4", "cornell_32x24_r4", "own_gems_48x36_r4"])
@@ -94,9 +115,9 @@ def test_row_tiles_with_partial_blocks(ctx, pkg, name):
         fr.release()
 
 
-def test_resolve_equals_the_separate_kernel_at_depth_8_and_larger_counts(ctx, pkg):
+def test_resolve_equals_the_separate_kernel_at_depth_8_and_larger_counts(ctx, ctx_sep, pkg):
     """rays_per_pixel 16, 64 and 256 (one, four and sixteen... pixels per block down to one): the in-pass sums against the separate
-    copyToPixel of the same library (MIRT_INPASS_RESOLVE off through a non-first pass), and against the CPU oracle's frame."""
+    copyToPixel of the same library (a context created with MIRT_INPASS_RESOLVE=0), and against the CPU oracle's frame."""
     from raytracing_amd.pyhost import render, scene
     fx, sc0 = load_fixture("cornell_teapot3_32x24_r4")
     for rpp, (w, h) in ((16, (40, 30)), (64, (24, 18)), (256, (12, 9))):
@@ -105,7 +126,7 @@ def test_resolve_equals_the_separate_kernel_at_depth_8_and_larger_counts(ctx, pk
         seeds = A.make_seeds(sc.total_rays, seed_base=rpp)
         a = render.FusedRenderer(ctx, ps, seeds=seeds, keep_acu=False)
         a.execute_render(bounces=8, fresh=True)
-        b = render.FusedRenderer(ctx, ps, seeds=seeds)
+        b = render.FusedRenderer(ctx_sep, ps, seeds=seeds)
         b.execute_render(bounces=8, fresh=False)
         assert np.array_equal(a.pixel.read(np.uint8), b.pixel.read(np.uint8)), rpp
         assert np.array_equal(bits(a.radiance.read(np.float32)), bits(b.radiance.read(np.float32))), rpp
@@ -142,7 +163,7 @@ def test_acu_is_only_optional_where_the_pass_resolves(ctx, pkg):
 @pytest.mark.parametrize("exact_only", [False, True], ids=["optimistic", "exact_only"])
 @pytest.mark.parametrize("rpp,size", [(1024, (7, 5)), (4096, (3, 2))])
 @pytest.mark.parametrize("name", ["cornell_32x24_r4", "cornell_teapot3_32x24_r4", "own_flat_32x24_r4"])
-def test_pixels_of_more_than_256_rays_resolve_block_by_block(ctx, pkg, name, rpp, size, exact_only):
+def test_pixels_of_more_than_256_rays_resolve_block_by_block(ctx, ctx_sep, pkg, name, rpp, size, exact_only):
     """BASELINE config 5's ray count (1024 = a 32 x 32 lens grid: four blocks of 256 ray ids per pixel) and the next square that is 256 times a
     power of two (4096: sixteen): the pass runs once per block of a pixel, in ray order, each launch going on from the sums the one before left
     (pt_launch.hpp FusedArgs::chunks) -- the reference's single chain of additions (A10 code.cl:1377-1380), cut at multiples of 256.  Against the
@@ -156,10 +177,11 @@ def test_pixels_of_more_than_256_rays_resolve_block_by_block(ctx, pkg, name, rpp
     sc = A.Scene(ps.d)
     seeds = A.make_seeds(sc.total_rays, seed_base=rpp + w)
     ctx.set_exact_only(exact_only)
+    ctx_sep.set_exact_only(exact_only)
     try:
-        b = render.FusedRenderer(ctx, ps, seeds=seeds)
+        b = render.FusedRenderer(ctx_sep, ps, seeds=seeds)
         b.execute_render(fresh=False)                                   # accumulator + the separate copyToPixel
-        deferred_samples = ctx.pass_deferred()
+        deferred_samples = ctx_sep.pass_deferred()
         for want_radiance in (True, False):
             a = render.FusedRenderer(ctx, ps, seeds=seeds, keep_acu=False, want_radiance=want_radiance)
             a.pixel.write(np.full(sc.width * sc.height * 4, 7, np.uint8))
@@ -184,19 +206,28 @@ def test_pixels_of_more_than_256_rays_resolve_block_by_block(ctx, pkg, name, rpp
             st = A.PassState(sc, seeds)
             A.run_pass(A.load_oracle(), sc, st)
             assert np.array_equal(b.pixel.read(np.uint8).reshape(-1, 4), st.pixel)
+        # a later pass of a progressive frame resolves block by block too: two passes against two passes of the separate kernel
+        a = render.FusedRenderer(ctx, ps, seeds=seeds)
+        for _ in range(2):
+            a.execute_render(fresh=False)
+        b.execute_render(fresh=False)
+        assert np.array_equal(a.pixel.read(np.uint8), b.pixel.read(np.uint8)) and np.array_equal(bits(a.acu.read(np.float32)), bits(b.acu.read(np.float32)))
+        assert np.array_equal(bits(a.radiance.read(np.float32)), bits(b.radiance.read(np.float32)))
+        a.release()
         b.release()
     finally:
         ctx.set_exact_only(False)
+        ctx_sep.set_exact_only(False)
 
 
-def test_row_tiles_of_pixels_of_1024_rays(ctx, pkg):
+def test_row_tiles_of_pixels_of_1024_rays(ctx, ctx_sep, pkg):
     """a row tile of the block-by-block resolve: its pixels are the whole frame's, nothing is written past them"""
     from raytracing_amd.pyhost import render, scene
     fx, sc0 = load_fixture("cornell_teapot3_32x24_r4")
     ps = scene.PackedScene(dict(sc0.d)).resized(5, 6, 1024)
     sc = A.Scene(ps.d)
     seeds = A.make_seeds(sc.total_rays, seed_base=99)
-    whole = render.FusedRenderer(ctx, ps, seeds=seeds)
+    whole = render.FusedRenderer(ctx_sep, ps, seeds=seeds)
     whole.execute_render(fresh=False)
     want = whole.pixel.read(np.uint8).reshape(-1, 4)
     for row0, nrows in [(0, 1), (2, 3), (5, 1)]:
