@@ -119,9 +119,19 @@ PT_DEV uint32_t f2u_uniform(float f) {
                          // 2.5-ulp forms -- the arithmetic of the reference built WITHOUT -cl-fp32-correctly-rounded-divide-sqrt.  A timing
                          // experiment only: no reference exists for its bits
 #endif
+// 1.0f / d as a value of its own.  Under the default contract (PT_PLAIN_DIV: 2.5 ulp allowed) the compiler is free to fold a reciprocal into the one product
+// that uses it, and does so when there is only one -- the any-hit mesh kernel keeps t alone of the triangle test's three products and came out an ulp
+// off the reference, whose 1 / div always has three uses (code.cl:260-277).  The empty asm keeps the quotient a quotient whatever its uses are.
+PT_DEV float rcp_plain(float d) {
+    float r = 1.0f / d;
+#if PT_PLAIN_DIV
+    asm volatile("" : "+v"(r));
+#endif
+    return r;
+}
 PT_DEV float rcp_refined(float d) {
 #if PT_PLAIN_DIV
-    return 1.0f / d;
+    return rcp_plain(d);
 #endif
     float r = __builtin_amdgcn_rcpf(d);
     float e = __builtin_fmaf(-d, r, 1.0f);
@@ -156,10 +166,10 @@ PT_DEV bool rcp_window(float x) { return (__float_as_uint(x) & 0x7FFFFFFFu) - 0x
 PT_DEV float rcp_exact(float x, bool dont_care = false) {
 #if PT_EXACT_FAST_DIV && PT_EXACT_FAST_NORM
     float r = rcp_refined(x);
-    if (__builtin_expect(!(dont_care || rcp_window(x)), 0)) r = 1.0f / x;   // rare lanes only: s_cbranch_execz skips it
+    if (__builtin_expect(!(dont_care || rcp_window(x)), 0)) r = rcp_plain(x);   // rare lanes only: s_cbranch_execz skips it
     return r;
 #else
-    return 1.0f / x;
+    return rcp_plain(x);
 #endif
 }
 

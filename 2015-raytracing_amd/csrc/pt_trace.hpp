@@ -86,7 +86,7 @@ PT_DEV bool tri_test(f3 o, f3 d, float cmin, float cmax, const float4 A, const f
     if (WAVE_CULL && __builtin_amdgcn_ballot_w64(!(div <= 0)) == 0ull) { t_out = 0.0f; beta_out = 0.0f; gamma_out = 0.0f; return false; }
     float idiv;
     if (FAST) idiv = rcp_refined(div);   // div <= 0 (incl. 0 -> NaN) and NaN lanes are rejected below whatever idiv is
-    else idiv = 1.0f / div;
+    else idiv = rcp_plain(div);
     f3 s = sub3(o, p0);
     float beta = dot3(cross3(s, d), e2) * idiv;
     float gamma = dot3(cross3(s, e1), d) * idiv;
@@ -291,7 +291,7 @@ template <bool FAST>
 PT_DEV SphereRay sphere_ray(f3 d) {
     SphereRay r;
     r.a = dot3(d, d);
-    r.inv2a = FAST ? rcp_refined(2.0f * r.a) : (1.0f / (2.0f * r.a));
+    r.inv2a = FAST ? rcp_refined(2.0f * r.a) : rcp_plain(2.0f * r.a);
     return r;
 }
 // ORDERED (the optimistic kernel): with a = d.d > 0 the two roots come out ordered, t0 = (-b - sq) / 2a <= t1 = (-b + sq) / 2a (sq >= 0 or NaN; sums

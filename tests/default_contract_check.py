@@ -64,6 +64,43 @@ def scenes(mirt, render, scene):
     return True
 
 
+def kernel_by_kernel(mirt, render, scene):
+    """The kernel-by-kernel path of the same library (the reference's fourteen kernels one by one, as its host enqueues them; fusion off) against the
+    reference's default build: every Ray, shadow Ray, Poi, accumulator and seed after one pass, on scenes with spheres, loose triangles and grid meshes."""
+    for name in ("basic_32x24_r4", "cornell_teapot3_32x24_r4", "own_gems_48x36_r4", "twoLights_32x24_r4"):
+        fx, sc0 = load_fixture(name)
+        ps = scene.PackedScene(dict(sc0.d)).resized(96, 54, 4)
+        sc = A.Scene(ps.d)
+        seeds = A.make_seeds(sc.total_rays, seed_base=5)
+        k = G.GpuRefKernels(DEFAULT_HSACO)
+        st = A.PassState(sc, seeds)
+        A.run_pass(k, sc, st)
+        ctx = mirt.Context(0)
+        ctx.set_fusion(0)
+        gr = render.GranularRenderer(ctx, ps, seeds=seeds)
+        try:
+            gr.execute_render()
+            rays, shadow, pois = gr.read("rays").view(A.RAY_DT), gr.read("shadow").view(A.RAY_DT), gr.read("pois").view(A.POI_DT)
+            checks = [("accumulators", gr.read("acu"), st.acu), ("seeds", gr.read("seeds"), st.seeds), ("pixels", gr.read("pixel"), st.pixel),
+                      ("matId", pois["matId"], st.pois["matId"]), ("atte", pois["atte"], st.pois["atte"])]
+            hit = st.pois["matId"] >= 0   # (p / normal of a vertex never hit, o / d of a dead ray: fields the reference leaves undefined, conftest.assert_state_equal)
+            checks += [("p", pois["p"][hit], st.pois["p"][hit]), ("normal", pois["normal"][hit], st.pois["normal"][hit])]
+            for tag, g_, w_ in (("rays", rays, st.rays), ("shadow rays", shadow, st.shadow)):
+                live = ~(np.isinf(w_["mint"]) & np.isinf(w_["maxt"]))
+                checks += [(tag + " mint", g_["mint"], w_["mint"]), (tag + " maxt", g_["maxt"], w_["maxt"]), (tag + " o", g_["o"][live], w_["o"][live]), (tag + " d", g_["d"][live], w_["d"][live])]
+            for tag, got, want in checks:
+                d = first_difference(f"{name} kernel by kernel, {tag}", np.ascontiguousarray(got), np.ascontiguousarray(want))
+                if d:
+                    print(json.dumps({"check": "granular", "scene": name, "ok": False, "difference": d}), flush=True)
+                    return False
+            print(json.dumps({"check": "granular", "scene": name, "ok": True}), flush=True)
+        finally:
+            k.release()
+            gr.release()
+            ctx.destroy()
+    return True
+
+
 def random_scenes(mirt, render, scene, count):
     """`count` generated scenes (tests/test_random_scenes.py: one to three loose and grid sets, grids of 1..7 cells per axis, crowded and empty cells, one to
     three lights) -- the optimistic pair, the exact kernel alone and the pass that resolves its own pixels, each against the reference's default build."""
@@ -168,6 +205,8 @@ def main():
     ok = True
     if "scenes" in which:
         ok = scenes(mirt, render, scene) and ok
+    if ok and "granular" in which:
+        ok = kernel_by_kernel(mirt, render, scene) and ok
     if ok and "random" in which:
         ok = random_scenes(mirt, render, scene, int(os.environ.get("MIRT_SOAK", "64"))) and ok
     if ok and "headline" in which:

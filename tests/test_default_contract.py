@@ -38,6 +38,15 @@ def test_every_scene_equals_the_default_build_of_the_reference():
 
 @pytest.mark.gpu
 @needs
+def test_kernel_by_kernel_path_equals_the_default_build_of_the_reference():
+    """the fourteen kernels one by one (fusion off) in the default-contract library: every buffer after a pass, four scenes"""
+    r, lines = run_check("granular")
+    assert r.returncode == 0, (lines[-1:] or r.stderr[-2000:])
+    assert len(lines) == 4 and all(l["ok"] for l in lines)
+
+
+@pytest.mark.gpu
+@needs
 def test_generated_scenes_equal_the_default_build_of_the_reference():
     """64 generated scenes (MIRT_SOAK=N: N) with grids of 1..7 cells per axis: the optimistic pair -- since round 4 this library has one: the optimistic
     kernel's structure with every quotient a plain division -- the exact kernel alone, and the in-pass resolve, against the reference's default build"""
