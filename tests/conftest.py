@@ -74,3 +74,20 @@ def assert_state_equal(tag, got, fx, prefix):
     hit = fx[f"{prefix}_pois_matId"] >= 0
     for f in ("p", "normal"):
         assert np.array_equal(bits(got["pois"][f][hit]), bits(fx[f"{prefix}_pois_{f}"][hit])), f"{tag}: pois.{f}"
+
+
+def assert_state_equals_pass_state(tag, got, st):
+    """the same comparison against a live pass state (oracle/a10_pass.PassState: structured rays / shadow / pois, acu, seeds) instead of a fixture"""
+    assert np.array_equal(bits(got["acu"]).reshape(-1, 4), bits(st.acu).reshape(-1, 4)), f"{tag}: acu"
+    assert np.array_equal(got["seeds"], st.seeds), f"{tag}: seeds"
+    for k, want in (("rays", st.rays), ("shadow", st.shadow)):
+        for f in ("mint", "maxt"):
+            assert np.array_equal(bits(got[k][f]), bits(want[f])), f"{tag}: {k}.{f}"
+        live = ~(np.isinf(want["mint"]) & np.isinf(want["maxt"]))
+        for f in ("o", "d"):
+            assert np.array_equal(bits(got[k][f][live]), bits(want[f][live])), f"{tag}: {k}.{f}"
+    assert np.array_equal(got["pois"]["matId"], st.pois["matId"]), f"{tag}: matId"
+    assert np.array_equal(bits(got["pois"]["atte"]), bits(st.pois["atte"])), f"{tag}: atte"
+    hit = st.pois["matId"] >= 0
+    for f in ("p", "normal"):
+        assert np.array_equal(bits(got["pois"][f][hit]), bits(st.pois[f][hit])), f"{tag}: pois.{f}"

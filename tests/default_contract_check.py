@@ -67,10 +67,18 @@ def scenes(mirt, render, scene):
 def kernel_by_kernel(mirt, render, scene):
     """The kernel-by-kernel path of the same library (the reference's fourteen kernels one by one, as its host enqueues them; fusion off) against the
     reference's default build: every Ray, shadow Ray, Poi, accumulator and seed after one pass, on scenes with spheres, loose triangles and grid meshes."""
-    for name in ("basic_32x24_r4", "cornell_teapot3_32x24_r4", "own_gems_48x36_r4", "twoLights_32x24_r4"):
-        fx, sc0 = load_fixture(name)
-        ps = scene.PackedScene(dict(sc0.d)).resized(96, 54, 4)
-        sc = A.Scene(ps.d)
+    from test_random_scenes import random_scene
+    _, rbase = load_fixture("cornell_teapot3_32x24_r4")
+    cases = [("basic_32x24_r4", None), ("cornell_teapot3_32x24_r4", None), ("own_gems_48x36_r4", None), ("twoLights_32x24_r4", None)]
+    cases += [(f"generated scene {i}", i) for i in range(int(os.environ.get("MIRT_SOAK_GRANULAR", "24")))]
+    for name, gen in cases:
+        if gen is None:
+            fx, sc0 = load_fixture(name)
+            ps = scene.PackedScene(dict(sc0.d)).resized(96, 54, 4)
+            sc = A.Scene(ps.d)
+        else:   # (sphere and triangle sets in grids of 1..3 cells per axis, meshes in 1..7: tests/test_random_scenes.py)
+            sc = random_scene(rbase, 1000 + gen, rpp=4)
+            ps = sc
         seeds = A.make_seeds(sc.total_rays, seed_base=5)
         k = G.GpuRefKernels(DEFAULT_HSACO)
         st = A.PassState(sc, seeds)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import a10_pass as A
-from conftest import bits, load_fixture
+from conftest import assert_state_equals_pass_state, bits, load_fixture
 from test_grid_build import expected_grid
 from test_gpu_parity import _variant, snapshot
 
@@ -117,6 +117,7 @@ def test_random_scene_all_paths_agree(ctx, pkg, seed):
     got = snapshot(gr)
     assert np.array_equal(bits(got["acu"]), bits(st.acu)) and np.array_equal(got["seeds"], st.seeds), "kernel by kernel"
     assert np.array_equal(got["pois"]["matId"], st.pois["matId"])
+    assert_state_equals_pass_state("kernel by kernel", got, st)   # every Ray, shadow Ray (a blocked one's stored t included) and vertex
     gr.release()
 
 
