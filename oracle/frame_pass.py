@@ -104,11 +104,12 @@ FRAME_KERNEL_ARGS = {   # argument kinds in the kernels' own order: B buffer, U 
 }
 
 
-def run_frame_gpu(fr, device=0):
+def run_frame_gpu(fr, device=0, default_build=False):
     """run_frame on the reference's own kernels as AMD's OpenCL toolchain builds them, on the device.  Same launch shapes as the reference
-    host: 2-D NDRange, local [8, 8], globals padded (A01: exactly cols x rows, its kernel has no range check)."""
+    host: 2-D NDRange, local [8, 8], globals padded (A01: exactly cols x rows, its kernel has no range check).  default_build: the code object built
+    WITHOUT -cl-fp32-correctly-rounded-divide-sqrt (program.build() without options, as the reference's own host builds it: the second contract)."""
     import ref_gpu as G
-    mod = G.GpuModule(os.path.join(HERE, "_ref", f"a{fr.assign:02d}_gfx950.hsaco"), FRAME_KERNEL_ARGS[fr.assign], device)
+    mod = G.GpuModule(os.path.join(HERE, "_ref", f"a{fr.assign:02d}_gfx950{'_default' if default_build else ''}.hsaco"), FRAME_KERNEL_ARGS[fr.assign], device)
     w, h = fr.width, fr.height
     g = [A._ceil(w, 8), A._ceil(h, 8)]
     pixels = np.zeros((w * h, 4), np.uint8)

@@ -109,6 +109,35 @@ def kernel_by_kernel(mirt, render, scene):
     return True
 
 
+def frames(mirt, render, scene):
+    """BASELINE configs 1-3 and the molecule mode at full size: the Assign01 / 04 / 07 frame kernels of the default-contract library against the reference's
+    code.cl built with ITS defaults (oracle/_ref/a0N_gfx950_default.hsaco), on the device: every pixel, and every ray's maxt."""
+    import frame_pass as F
+    from test_frames import fixture, resized
+    ctx = mirt.Context(0)
+    try:
+        for name, size in (("frame_a01_512x512", None), ("frame_a04_parliament_96x64", (1024, 1024)), ("frame_a04_teapot_160x120", (1024, 1024)),
+                           ("frame_a07_parliament_n16_160x120", (1920, 1080)), ("frame_a07_teapot_n2_160x120", (1920, 1080)), ("frame_a07_teapot_n8_160x120", (1920, 1080)),
+                           ("frame_a07_mol_3IZ4_n16_96x64", (1920, 1080)), ("frame_a07_mol_c60_n4_160x120", (1920, 1080)), ("frame_a07_own_terrain_n5_96x64", (1920, 1080)),
+                           ("frame_a04_house_160x120", (1024, 1024)), ("frame_a07_house_n2_160x120", (1920, 1080)), ("frame_a07_house_n8_160x120", (1920, 1080))):
+            _, d = fixture(name)
+            if size:
+                d = resized(d, *size)
+            want_px, want_rays = F.run_frame_gpu(F.Frame(d), default_build=True)
+            px, rays = render.render_frame(ctx, render.FramePacked(d))
+            diff = first_difference(name + " pixels", np.ascontiguousarray(px), np.ascontiguousarray(want_px))
+            if not diff and want_rays is not None and rays is not None:
+                got = np.ascontiguousarray(rays).view(A.RAY_DT)
+                diff = first_difference(name + " rays.maxt", np.ascontiguousarray(got["maxt"]), np.ascontiguousarray(want_rays["maxt"]))
+            if diff:
+                print(json.dumps({"check": "frames", "frame": name, "ok": False, "difference": diff}), flush=True)
+                return False
+            print(json.dumps({"check": "frames", "frame": name, "ok": True}), flush=True)
+    finally:
+        ctx.destroy()
+    return True
+
+
 def random_scenes(mirt, render, scene, count):
     """`count` generated scenes (tests/test_random_scenes.py: one to three loose and grid sets, grids of 1..7 cells per axis, crowded and empty cells, one to
     three lights) -- the optimistic pair, the exact kernel alone and the pass that resolves its own pixels, each against the reference's default build."""
@@ -213,6 +242,8 @@ def main():
     ok = True
     if "scenes" in which:
         ok = scenes(mirt, render, scene) and ok
+    if ok and "frames" in which:
+        ok = frames(mirt, render, scene) and ok
     if ok and "granular" in which:
         ok = kernel_by_kernel(mirt, render, scene) and ok
     if ok and "random" in which:

@@ -38,6 +38,16 @@ def test_every_scene_equals_the_default_build_of_the_reference():
 
 @pytest.mark.gpu
 @needs
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "a07_gfx950_default.hsaco")), reason="needs the default builds of Assign01/04/07 (make -C oracle ref_gpu)")
+def test_frame_kernels_equal_the_default_builds_of_the_reference():
+    """BASELINE configs 1-3 (Assign01 / 04 / 07) and the molecule mode at full size, twelve frames: every pixel and every ray's maxt"""
+    r, lines = run_check("frames")
+    assert r.returncode == 0, (lines[-1:] or r.stderr[-2000:])
+    assert len(lines) == 12 and all(l["ok"] for l in lines)
+
+
+@pytest.mark.gpu
+@needs
 def test_kernel_by_kernel_path_equals_the_default_build_of_the_reference():
     """the fourteen kernels one by one (fusion off) in the default-contract library: every buffer after a pass -- every Ray, shadow Ray (the stored t of
     a blocked one included: it caught the compiler folding a single-use reciprocal into its product), vertex, accumulator, seed, pixel -- on four fixture
