@@ -25,7 +25,9 @@ let addon = null;
 function native() {
   if (!addon) {
     try {
-      addon = require(path.join(__dirname, "..", "mirt.node"));
+      // MIRT_CONTRACT=default: the addon over libmirt_default.so -- the kernels built as the reference's own host builds its program (program.build() without
+      // options, A10 code.js:599: AMD's 2.5-ulp division); otherwise the correctly rounded contract (the one a CPU checker can reproduce)
+      addon = require(path.join(__dirname, "..", process.env.MIRT_CONTRACT === "default" ? "mirt_default.node" : "mirt.node"));
     } catch (e) {
       throw new Error("mirt.node is not built (python -c 'import __graft_entry__ as g; g.build()'): " + e.message);
     }

@@ -61,6 +61,7 @@ def play(trace, blob, k):
     import ctypes as C
     bufs, kern, reads, named, keep = {}, {}, [], {}, {}
     roles = {}
+    gpu = getattr(k, "on_gpu", False)   # oracle/ref_gpu.GpuRefKernels: buffer arguments are device mirrors of the host arrays (buf / upload / flush)
     for e in trace["events"]:
         op = e["op"]
         if op == "createBuffer":
@@ -76,7 +77,11 @@ def play(trace, blob, k):
             data = np.frombuffer(payload(e, blob), np.uint8)
             assert len(data) == e["bytes"]
             bufs[e["buffer"]][e["offset"]:e["offset"] + e["bytes"]] = data
+            if gpu:
+                k.upload(bufs[e["buffer"]])
         elif op == "enqueueReadBuffer":
+            if gpu:
+                k.flush()
             reads.append(bufs[e["buffer"]][e["offset"]:e["offset"] + e["bytes"]].tobytes())
         elif op == "enqueueNDRangeKernel":
             kk = kern[e["kernel"]]
@@ -91,7 +96,7 @@ def play(trace, blob, k):
                 tag, v = kk["args"][i]
                 if kind == "B":
                     assert tag == "B", f"{name} arg {i}: expected a buffer"
-                    args.append(bufs[v].ctypes.data_as(C.c_void_p))
+                    args.append(k.buf(bufs[v]) if gpu else bufs[v].ctypes.data_as(C.c_void_p))
                 else:
                     assert tag == "S" and len(v) == SCALAR_BYTES[kind], f"{name} arg {i}: {len(v)} bytes for kind {kind}"
                     if kind == "U":
@@ -105,10 +110,14 @@ def play(trace, blob, k):
             assert e["dim"] == len(e["global"]) == (2 if name == "initTrace" else 1)
             getattr(k, name)(*args, *e["global"])
         elif op == "release" and e["kind"] == "buffer":
+            if gpu:
+                k.flush()
             if e["id"] in roles:
                 named[roles[e["id"]]] = bufs[e["id"]]
             else:
                 del bufs[e["id"]]
+    if gpu:
+        k.flush()
     for i, r in roles.items():   # traces that never release
         named.setdefault(r, bufs.get(i))
     return {"reads": reads, "buffers": named}

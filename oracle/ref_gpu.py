@@ -126,6 +126,12 @@ class GpuModule:
             m = self.mirrors[id(a)] = (a, p.value)
         return m[1]
 
+    def upload(self, a):
+        """the host array changed (a host write of the call-trace player): refresh its device mirror, if it has one"""
+        m = self.mirrors.get(id(a))
+        if m is not None and a.nbytes:
+            chk(hip().hipMemcpy(C.c_void_p(m[1]), a.ctypes.data_as(C.c_void_p), a.nbytes, 1), "hipMemcpy H2D")
+
     def flush(self):
         """copy every mirror back into its numpy array"""
         chk(hip().hipDeviceSynchronize(), "hipDeviceSynchronize")

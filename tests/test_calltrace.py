@@ -215,3 +215,29 @@ def test_replayed_reference_host_stream_matches_compiled_reference(name, tmp_pat
         off += n
     assert off == len(raw)
     check_against_expectation(name, reads, open(out + ".acu.bin", "rb").read(), open(out + ".seeds.bin", "rb").read())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(os.path.join(ROOT, "oracle", "_ref", "a10_gfx950_default.hsaco")) and os.path.exists(os.path.join(ROOT, "2015-raytracing_amd", "mirt_default.node"))),
+                    reason="needs the reference's default build and mirt_default.node")
+@pytest.mark.parametrize("fusion", ["0", "2"])
+@pytest.mark.parametrize("name", ["cornell_320x240_k2_p2", "threeLights_160x120_k3_p3"])
+def test_replayed_stream_on_the_references_own_build_contract(name, fusion, tmp_path):
+    """The same recorded streams of the unmodified page script under the SECOND numerics contract: replayed through webcl.js -> mirt_default.node ->
+    libmirt_default.so (MIRT_CONTRACT=default), kernel by kernel and fused by the runtime, against the stream played on the reference's code.cl as its own
+    host builds it (program.build() without options; oracle/_ref/a10_gfx950_default.hsaco, on the GPU): every read-back, the accumulator, the seeds.
+    (The two traces with more than one ray per pixel: at one, the reference's initTrace races on seeds[column] on a GPU, oracle/ref_gpu.py.)"""
+    import ref_gpu as G
+    trace, blob = CT.load_trace(CT.golden_prefix(name))
+    k = G.GpuRefKernels(os.path.join(ROOT, "oracle", "_ref", "a10_gfx950_default.hsaco"))
+    try:
+        want = CT.play(trace, blob, k)
+    finally:
+        k.release()
+    out = str(tmp_path / "r")
+    rep = json.loads(run_node(os.path.join(HOST, "replay.js"), CT.golden_prefix(name), out, env=dict(os.environ, MIRT_FUSION=fusion, MIRT_CONTRACT="default")))
+    assert (rep["fusedPasses"] > 0) == (fusion == "2"), rep
+    raw = open(out + ".reads.bin", "rb").read()
+    assert raw == b"".join(want["reads"]), "read-backs"
+    assert open(out + ".acu.bin", "rb").read() == want["buffers"]["acu"].tobytes(), "accumulator"
+    assert open(out + ".seeds.bin", "rb").read() == want["buffers"]["seeds"].tobytes(), "seeds"

@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import HOST, OWN_SCENES, PAGE, bits, load_fixture
+import sys
+
+from conftest import HOST, OWN_SCENES, PAGE, ROOT, bits, load_fixture
 
 node = shutil.which("node")
 pytestmark = pytest.mark.skipif(node is None, reason="node is not installed")
@@ -235,6 +237,34 @@ def test_node_device_group_render_n_tiles(tmp_path, flags):
     assert "gather routes per tile: " + " ".join(["local"] * n) + ";" in log, log   # every context shares device 0 in this rehearsal
     assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), fx["pixel"])
     assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(fx["radiance"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(os.path.join(ROOT, "oracle", "_ref", "a10_gfx950_default.hsaco")) and os.path.exists(os.path.join(ROOT, "2015-raytracing_amd", "mirt_default.node"))),
+                    reason="needs the reference's default build and mirt_default.node")
+@pytest.mark.parametrize("flags", [[], ["--granular"], ["--gpus", "1"]])
+def test_node_host_on_the_references_own_build_contract(tmp_path, flags):
+    """MIRT_CONTRACT=default: host/webcl.js loads mirt_default.node -> libmirt_default.so, the kernels built as the reference's own host builds its program
+    (program.build() without options, A10 code.js:599: 2.5-ulp division).  gems.xml (three grid meshes) through the Node CLI -- fused, kernel by kernel, and
+    through a device group -- against the reference's code.cl compiled with ITS defaults and run on the GPU, same seeds: frame and radiance sums."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import a10_pass as A
+    import ref_gpu as G
+    fx, sc = load_fixture("own_gems_48x36_r4")
+    seeds = np.asarray(fx["seeds_in"], np.int32)
+    k = G.GpuRefKernels(os.path.join(ROOT, "oracle", "_ref", "a10_gfx950_default.hsaco"))
+    st = A.PassState(sc, seeds)
+    try:
+        A.run_pass(k, sc, st)
+    finally:
+        k.release()
+    sfile = str(tmp_path / "seeds.i32")
+    seeds.tofile(sfile)
+    out = str(tmp_path / "frame.rgba")
+    run_node(os.path.join(HOST, "cli.js"), "render", os.path.join(PAGE, "scenes", "gems.xml"), "48", "36", "4", "1", out, "--seeds", sfile, *flags,
+             env=dict(os.environ, MIRT_CONTRACT="default"))
+    assert np.array_equal(np.fromfile(out, np.uint8).reshape(-1, 4), st.pixel)
+    assert np.array_equal(bits(np.fromfile(out + ".radiance.f32", np.float32).reshape(-1, 4)), bits(A.radiance_sums(st.acu, 4)))
 
 
 @pytest.mark.gpu
