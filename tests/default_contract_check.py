@@ -138,6 +138,35 @@ def frames(mirt, render, scene):
     return True
 
 
+def big_pixels(mirt, render, scene):
+    """1024 rays per pixel (BASELINE config 5's 32 x 32 lens grid): the pass resolving its pixels block by block, four launches, without an accumulator"""
+    ctx = mirt.Context(0)
+    k = G.GpuRefKernels(DEFAULT_HSACO)
+    try:
+        for name in ("cornell_32x24_r4", "cornell_teapot3_32x24_r4"):
+            fx, sc0 = load_fixture(name)
+            ps = scene.PackedScene(dict(sc0.d)).resized(6, 4, 1024)
+            sc = A.Scene(ps.d)
+            seeds = A.make_seeds(sc.total_rays, seed_base=3)
+            st = A.PassState(sc, seeds)
+            A.run_pass(k, sc, st, bounces=8)
+            fr = render.FusedRenderer(ctx, ps, seeds=seeds, keep_acu=False)
+            fr.execute_render(bounces=8, fresh=True)
+            checks = (("seeds", fr.seeds.read(np.int32), st.seeds), ("pixels", fr.pixel.read(np.uint8), st.pixel),
+                      ("radiance", fr.radiance.read(np.float32), A.radiance_sums(st.acu, 1024)))
+            fr.release()
+            for tag, got, want in checks:
+                d = first_difference(f"{name} x 1024 rays per pixel, {tag}", np.asarray(got), np.asarray(want))
+                if d:
+                    print(json.dumps({"check": "big_pixels", "scene": name, "ok": False, "difference": d}), flush=True)
+                    return False
+            print(json.dumps({"check": "big_pixels", "scene": name, "ok": True}), flush=True)
+    finally:
+        k.release()
+        ctx.destroy()
+    return True
+
+
 def random_scenes(mirt, render, scene, count):
     """`count` generated scenes (tests/test_random_scenes.py: one to three loose and grid sets, grids of 1..7 cells per axis, crowded and empty cells, one to
     three lights) -- the optimistic pair, the exact kernel alone and the pass that resolves its own pixels, each against the reference's default build."""
@@ -242,6 +271,8 @@ def main():
     ok = True
     if "scenes" in which:
         ok = scenes(mirt, render, scene) and ok
+    if ok and "big_pixels" in which:
+        ok = big_pixels(mirt, render, scene) and ok
     if ok and "frames" in which:
         ok = frames(mirt, render, scene) and ok
     if ok and "granular" in which:

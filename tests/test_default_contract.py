@@ -48,6 +48,15 @@ def test_frame_kernels_equal_the_default_builds_of_the_reference():
 
 @pytest.mark.gpu
 @needs
+def test_pixels_of_1024_rays_equal_the_default_build_of_the_reference():
+    """config 5's ray count: the block-by-block in-pass resolve (four launches, no accumulator) under the default contract, depth 8, two scenes"""
+    r, lines = run_check("big_pixels")
+    assert r.returncode == 0, (lines[-1:] or r.stderr[-2000:])
+    assert len(lines) == 2 and all(l["ok"] for l in lines)
+
+
+@pytest.mark.gpu
+@needs
 def test_kernel_by_kernel_path_equals_the_default_build_of_the_reference():
     """the fourteen kernels one by one (fusion off) in the default-contract library: every buffer after a pass -- every Ray, shadow Ray (the stored t of
     a blocked one included: it caught the compiler folding a single-use reciprocal into its product), vertex, accumulator, seed, pixel -- on four fixture
