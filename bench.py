@@ -458,6 +458,21 @@ def main():
         except Exception as e:   # sub-records never cost the headline line
             log(f"extras skipped: {type(e).__name__}: {e}")
             out["extras_error"] = f"{type(e).__name__}: {e}"
+        if os.environ.get("MIRT_CONTRACT") != "default" and os.path.exists(os.path.join(ROOT, "2015-raytracing_amd", "libmirt_default.so")):
+            # the SECOND numerics contract -- libmirt_default.so, the kernels built as the reference's own host builds its program (2.5-ulp division,
+            # DESIGN.md section 2) -- on the same frame: a process of its own (a process loads one libmirt), started as a child, three timed steps
+            try:
+                import subprocess
+                env = dict(os.environ, MIRT_CONTRACT="default")
+                env.pop("MIRT_LIB_PATH", None)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras", "--no-depth5"],
+                                   env=env, capture_output=True, text=True, timeout=240)
+                d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["default_contract"] = {"library": "libmirt_default.so", "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                                           "launch_ms": d["roofline"]["launch_ms"], "frac": d["roofline"]["frac"],
+                                           "note": "the reference as its own host builds it (program.build() without options); bit-exact against that build: tests/test_default_contract.py"}
+            except Exception as e:
+                log(f"default-contract record skipped: {type(e).__name__}: {e}")
     ctx.destroy()
     if use_dist:
         dist.destroy_process_group()
