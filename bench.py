@@ -13,7 +13,7 @@ mod 2147483646) generated on the device.  One "step" is one such frame: initTrac
 through mirt_render_first_pass: ONE fused launch that also resolves the pixels (round 4: no per-ray accumulator, 8 B per sample + 20 B per
 pixel of HBM traffic; --keep-acu: the accumulator written per ray as a progressive second pass would need it).  Beside the headline the
 default run reports the grid kernel (`grid_scene`: cornell_teapot3) and BASELINE configs 2 / 3 (`frames`), each with a roofline fraction and a
-bounded CPU baseline (--no-extras skips them).
+bounded CPU baseline, and the same frame on the second numerics contract (`default_contract`: libmirt_default.so, in a child process) (--no-extras skips them).
 Inputs (scene buffers, seeds) are resident in HBM before the timed region.
 
 N > 1: one process per GPU; the frame is cut into N contiguous row tiles (ray ids stay global, so the
